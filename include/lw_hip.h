@@ -1,0 +1,135 @@
+/*
+ * lw_hip.h — C ABI of the MI355X (gfx950) NTT + MSM backend for lambdaworks.
+ *
+ * This is the drop-in boundary for the reference's data-parallel prover hot path.  Each entry point cites
+ * the reference interface it replaces (paths relative to the lambdaworks tree, v0.11.0):
+ *
+ *   - lw_hip_ntt / lw_hip_ntt_device        <->  evaluate_fft_cuda / interpolate_fft_cuda
+ *                                                (math/src/fft/gpu/cuda/polynomial.rs:16-49), i.e. the backend arm
+ *                                                of Polynomial::evaluate_fft / interpolate_fft
+ *                                                (math/src/fft/polynomial.rs:54-62,103-110)
+ *   - lw_polynomial_evaluate_fft            <->  Polynomial::evaluate_fft / evaluate_offset_fft
+ *                                                (math/src/fft/polynomial.rs:25-68,74-82)
+ *   - lw_polynomial_interpolate_fft         <->  Polynomial::interpolate_fft / interpolate_offset_fft
+ *                                                (math/src/fft/polynomial.rs:87-127)
+ *   - lw_hip_msm / lw_hip_msm_device        <->  msm::pippenger::msm (math/src/msm/pippenger.rs:18-32)
+ *   - lw_hip_init / lw_hip_shutdown         <->  CudaState::new (math/src/fft/gpu/cuda/state.rs:29-38); the
+ *                                                reference builds and drops device state on every call, this
+ *                                                library keeps one context (twiddle caches, scratch, streams)
+ *   - error codes                           <->  FFTError (math/src/fft/errors.rs:12-20), MSMError
+ *                                                (math/src/msm/naive.rs:7-9), CudaError
+ *                                                (gpu/src/cuda/abstractions/errors.rs:3-21)
+ *
+ * Data crosses the boundary bit-for-bit as the reference keeps it in memory (no conversion, as
+ * math/src/gpu/cuda/field/element.rs:30-42): a field element is UnsignedInteger{limbs:[u64;N]} with
+ * limbs[0] MOST significant, in Montgomery form; a projective point is X,Y,Z consecutive; an Fp2
+ * coordinate is [c0,c1]; MSM scalars are canonical (non-Montgomery) UnsignedInteger<4>.
+ *
+ * All functions return 0 on success or a negative lw_status_t; lw_hip_last_error() gives a thread-local
+ * message.  No exceptions or panics cross the ABI.  The caller owns every buffer; nothing is retained.
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry point fails with
+ * LW_ERR_NO_DEVICE.
+ */
+#ifndef LW_HIP_H
+#define LW_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LW_FIELD_STARK252 = 0,      /* field_name() == "stark256" (stark_252_prime_field.rs:26-28) */
+    LW_FIELD_BLS12_381_FR = 1,  /* bls12_381/default_types.rs:25-30 */
+    LW_FIELD_BABYBEAR = 2       /* field_name() == "babybear31" (babybear.rs:33-35, babybear_u32.rs:21-23) */
+} lw_field_t;
+
+typedef enum {
+    LW_LAYOUT_U64_LIMBS_MS_FIRST = 0, /* MontgomeryBackendPrimeField<_,4>: 4 x u64, R = 2^256 */
+    LW_LAYOUT_BABYBEAR_U32_R32 = 1,   /* U32MontgomeryBackendPrimeField: one u32, R = 2^32 (babybear_u32.rs:6) */
+    LW_LAYOUT_BABYBEAR_U64_R64 = 2,   /* MontgomeryBackendPrimeField<_,1>: one u64, R = 2^64 (babybear.rs:19-20) */
+    LW_LAYOUT_EXT4_INTERLEAVED = 3    /* Degree4BabyBearExtensionField values: 4 x u64 (R = 2^64) per element,
+                                         domain in the base field (quartic_babybear.rs:16-19,155-166) */
+} lw_layout_t;
+
+typedef enum { LW_DIR_FORWARD = 0, LW_DIR_INVERSE = 1 /* scaled by N^-1 */ } lw_dir_t;
+
+typedef enum {
+    LW_CURVE_BLS12_381_G1 = 0, /* 3 x 6 u64 per point */
+    LW_CURVE_BN254_G1 = 1,     /* 3 x 4 u64 */
+    LW_CURVE_BN254_G2 = 2,     /* 3 x 2 x 4 u64 */
+    LW_CURVE_BLS12_381_G2 = 3  /* 3 x 2 x 6 u64 */
+} lw_curve_t;
+
+typedef enum {
+    LW_OK = 0,
+    LW_ERR_INPUT_NOT_POW2 = -1,  /* FFTError::InputError */
+    LW_ERR_ORDER_TOO_LARGE = -2, /* FFTError::OrderError */
+    LW_ERR_ROOT_OF_UNITY = -3,   /* FFTError::RootOfUnityError / FieldError::RootOfUnityError */
+    LW_ERR_LENGTH_MISMATCH = -4, /* MSMError::LengthMismatch */
+    LW_ERR_NO_DEVICE = -5,       /* CudaError::DeviceNotFound */
+    LW_ERR_ALLOC = -6,           /* CudaError::AllocateMemory */
+    LW_ERR_LAUNCH = -7,          /* CudaError::Launch / FunctionError */
+    LW_ERR_COMM = -8,
+    LW_ERR_BAD_ARG = -9,
+    LW_ERR_INV_ZERO = -10        /* FieldError::InvZeroError (zero coset offset) */
+} lw_status_t;
+
+typedef struct {
+    double last_ntt_ms;      /* host wall time of the last lw_hip_ntt* call */
+    double last_msm_ms;
+    uint64_t ntt_calls, msm_calls;
+    uint64_t twiddle_bytes;  /* device bytes held by twiddle caches */
+    uint64_t scratch_bytes;
+} lw_timings_t;
+
+/* ---- context ---- */
+int lw_hip_init(const int *device_ids, int n_devices); /* NULL,0 -> current device */
+void lw_hip_shutdown(void);
+int lw_hip_device_count(void);
+const char *lw_hip_last_error(void);
+int lw_hip_get_timings(lw_timings_t *out);
+size_t lw_hip_field_elem_bytes(lw_field_t field, lw_layout_t layout);
+size_t lw_hip_curve_point_bytes(lw_curve_t curve);
+
+/* ---- NTT backend seam ----
+ * `in` holds `batch` transforms of 2^log2n elements, `batch_stride_elems` apart (0 -> dense).  Forward:
+ * natural-order coefficients -> natural-order evaluations at w^i.  Inverse: evaluations -> coefficients,
+ * already multiplied by N^-1.  coset_offset (one domain-field element in the same layout's base word, or
+ * NULL): forward evaluates on offset*w^i, inverse divides the result by offset^i.  `in` may alias `out`.
+ * log2n > TWO_ADICITY -> LW_ERR_ROOT_OF_UNITY; log2n > 63 -> LW_ERR_ORDER_TOO_LARGE. */
+int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t log2n,
+               uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null);
+
+/* Same, on device-resident buffers; `hip_stream` is a hipStream_t (NULL = default stream); asynchronous. */
+int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                      uint32_t log2n, uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null,
+                      void *hip_stream);
+
+/* ---- Polynomial FFT API (host buffers, reference semantics) ----
+ * evaluate: len = max(coeff_len, domain_size).next_power_of_two() * blowup_factor where coeff_len is
+ * taken after stripping trailing zero coefficients (Polynomial::new); writes *out_len elements.  Call with
+ * out == NULL to query *out_len.  Zero polynomial -> *out_len zeros.  Non-power-of-two len ->
+ * LW_ERR_INPUT_NOT_POW2. */
+int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void *coeffs, size_t n_coeffs,
+                               size_t blowup_factor, size_t domain_size, const void *offset_or_null, void *out,
+                               size_t out_capacity_elems, size_t *out_len);
+/* interpolate: n must be a power of two; writes all n coefficients and reports in *coeff_len the length
+ * after Polynomial::new would strip trailing zeros. */
+int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const void *evals, size_t n,
+                                  const void *offset_or_null, void *out_coeffs, size_t *coeff_len);
+
+/* ---- MSM ----
+ * scalars: n x 4 u64, canonical integers, MS limb first (callers pass .representative()).
+ * points: n projective points, not necessarily normalised (Z != 1 allowed), identity = (0:1:0).
+ * out_point: one projective point (same layout); only its affine image is canonical. */
+int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, const void *points, size_t n_points,
+               void *out_point);
+int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n,
+                      void *out_point_host, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,389 @@
+// extern "C" boundary (include/lw_hip.h) + context implementation.
+#include <stdarg.h>
+#include <string.h>
+#include <chrono>
+#include <vector>
+#include "context.h"
+#include "field.cuh"
+
+namespace lw {
+
+thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int DeviceBuf::ensure(size_t need) {
+    if (need <= bytes && p) return LW_OK;
+    if (p) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    if (need == 0) need = 256;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        return LW_ERR_ALLOC;
+    }
+    bytes = need;
+    return LW_OK;
+}
+void DeviceBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+static int init_locked(Context &c, const int *device_ids, int n_devices) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return LW_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    if (device_ids && n_devices > 0) {
+        dev = device_ids[0];
+        if (dev < 0 || dev >= count) {
+            set_error("device id %d out of range (0..%d)", dev, count - 1);
+            return LW_ERR_NO_DEVICE;
+        }
+        LW_HIP_CHECK(hipSetDevice(dev), LW_ERR_NO_DEVICE);
+    } else {
+        LW_HIP_CHECK(hipGetDevice(&dev), LW_ERR_NO_DEVICE);
+    }
+    hipDeviceProp_t prop;
+    LW_HIP_CHECK(hipGetDeviceProperties(&prop, dev), LW_ERR_NO_DEVICE);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library ships gfx950 code objects only", dev, prop.gcnArchName);
+        return LW_ERR_NO_DEVICE;
+    }
+    c.device = dev;
+    c.initialised = true;
+    return LW_OK;
+}
+
+int ensure_init() {
+    Context &c = ctx();
+    if (c.initialised) return LW_OK;
+    return init_locked(c, nullptr, 0);
+}
+
+// defined in ntt256.hip / ntt_bb.hip / msm.hip
+int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
+                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream);
+int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
+                  uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
+int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
+               hipStream_t stream);
+
+static uint32_t two_adicity(lw_field_t f) {
+    switch (f) {
+        case LW_FIELD_STARK252: return Stark252::TWO_ADICITY;
+        case LW_FIELD_BLS12_381_FR: return Fr381::TWO_ADICITY;
+        default: return BabyBear::TWO_ADICITY;
+    }
+}
+
+static int check_field_layout(lw_field_t field, lw_layout_t layout) {
+    bool ok = false;
+    if (field == LW_FIELD_STARK252 || field == LW_FIELD_BLS12_381_FR) ok = layout == LW_LAYOUT_U64_LIMBS_MS_FIRST;
+    if (field == LW_FIELD_BABYBEAR)
+        ok = layout == LW_LAYOUT_BABYBEAR_U32_R32 || layout == LW_LAYOUT_BABYBEAR_U64_R64 || layout == LW_LAYOUT_EXT4_INTERLEAVED;
+    if (!ok) {
+        set_error("field %d does not support layout %d", (int)field, (int)layout);
+        return LW_ERR_BAD_ARG;
+    }
+    return LW_OK;
+}
+
+// reference layout (u64, MS limb first) -> internal 8 x u32, LS first
+static void words_from_ref(const void *ref, uint32_t *w) {
+    const uint32_t *m = (const uint32_t *)ref;
+    for (int k = 0; k < 8; k++) w[k] = m[2 * (3 - k / 2) + (k & 1)];
+}
+
+static int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                             uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (dir != LW_DIR_FORWARD && dir != LW_DIR_INVERSE) {
+        set_error("bad direction %d", (int)dir);
+        return LW_ERR_BAD_ARG;
+    }
+    if (log2n > 63) {   // get_twiddles: order > 63 -> FFTError::OrderError (roots_of_unity.rs:70-72)
+        set_error("order %u > 63", log2n);
+        return LW_ERR_ORDER_TOO_LARGE;
+    }
+    if (log2n > two_adicity(field)) {   // traits.rs:88-90
+        set_error("no primitive 2^%u-th root of unity in this field", log2n);
+        return LW_ERR_ROOT_OF_UNITY;
+    }
+    if (log2n > 34) {
+        set_error("2^%u elements exceed device memory", log2n);
+        return LW_ERR_ALLOC;
+    }
+    if (batch == 0) return LW_OK;
+    if (stride != 0 && stride < ((size_t)1 << log2n)) {
+        set_error("batch stride %zu < transform length", stride);
+        return LW_ERR_BAD_ARG;
+    }
+    if (!d_in || !d_out) {
+        set_error("null buffer");
+        return LW_ERR_BAD_ARG;
+    }
+    if (field == LW_FIELD_BABYBEAR) return ntt_bb_device(c, layout, dir, d_in, d_out, log2n, batch, stride, coset, stream);
+    uint32_t cw[8];
+    if (coset) words_from_ref(coset, cw);
+    return ntt256_device(c, (int)field, dir, d_in, d_out, log2n, batch, stride, coset ? cw : nullptr, stream);
+}
+
+}  // namespace lw
+
+using namespace lw;
+
+extern "C" {
+
+int lw_hip_init(const int *device_ids, int n_devices) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    return init_locked(c, device_ids, n_devices);
+}
+
+void lw_hip_shutdown(void) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!c.initialised) return;
+    (void)hipDeviceSynchronize();
+    for (int f = 0; f < 3; f++)
+        for (int d = 0; d < 2; d++) {
+            c.tw[f][d].buf.release();
+            c.tw[f][d].valid = false;
+        }
+    c.scratch.release();
+    c.small.release();
+    for (int i = 0; i < 2; i++) {
+        c.coset[i].lo.release();
+        c.coset[i].hi.release();
+        c.coset[i].valid = false;
+    }
+    c.msm_ws.release();
+    c.host_io_a.release();
+    c.host_io_b.release();
+    c.initialised = false;
+}
+
+int lw_hip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char *lw_hip_last_error(void) { return g_last_error.c_str(); }
+
+int lw_hip_get_timings(lw_timings_t *out) {
+    if (!out) return LW_ERR_BAD_ARG;
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    *out = c.timings;
+    return LW_OK;
+}
+
+size_t lw_hip_field_elem_bytes(lw_field_t field, lw_layout_t layout) {
+    if (field == LW_FIELD_STARK252 || field == LW_FIELD_BLS12_381_FR) return 32;
+    switch (layout) {
+        case LW_LAYOUT_BABYBEAR_U32_R32: return 4;
+        case LW_LAYOUT_BABYBEAR_U64_R64: return 8;
+        case LW_LAYOUT_EXT4_INTERLEAVED: return 32;
+        default: return 0;
+    }
+}
+
+size_t lw_hip_curve_point_bytes(lw_curve_t curve) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return 144;
+        case LW_CURVE_BN254_G1: return 96;
+        case LW_CURVE_BN254_G2: return 192;
+        case LW_CURVE_BLS12_381_G2: return 288;
+        default: return 0;
+    }
+}
+
+int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
+                      uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null, void *hip_stream) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = ntt_device_locked(c, field, layout, dir, d_in, d_out, log2n, batch, batch_stride_elems, coset_offset_or_null,
+                           (hipStream_t)hip_stream);
+    c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.ntt_calls++;
+    return rc;
+}
+
+int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t log2n, uint32_t batch,
+               size_t batch_stride_elems, const void *coset_offset_or_null) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (log2n > 63) { set_error("order %u > 63", log2n); return LW_ERR_ORDER_TOO_LARGE; }
+    if (log2n > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
+    if (batch == 0) return LW_OK;
+    if (!in || !out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t eb = lw_hip_field_elem_bytes(field, layout);
+    const size_t n = (size_t)1 << log2n;
+    const size_t stride = batch_stride_elems ? batch_stride_elems : n;
+    if (stride < n) { set_error("batch stride %zu < transform length", stride); return LW_ERR_BAD_ARG; }
+    const size_t span = ((size_t)(batch - 1) * stride + n) * eb;
+    if (c.host_io_a.ensure(span) || c.host_io_b.ensure(span)) return LW_ERR_ALLOC;
+    LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, in, span, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    rc = ntt_device_locked(c, field, layout, dir, c.host_io_a.p, c.host_io_b.p, log2n, batch, stride, coset_offset_or_null, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipStreamSynchronize(0), LW_ERR_LAUNCH);
+    if (stride == n) {
+        LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, span, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    } else {   // leave the gaps between strided transforms untouched
+        LW_HIP_CHECK(hipMemcpy2D(out, stride * eb, c.host_io_b.p, stride * eb, n * eb, batch, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    }
+    c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.ntt_calls++;
+    return LW_OK;
+}
+
+static bool elem_is_zero(const unsigned char *p, size_t eb) {
+    for (size_t i = 0; i < eb; i++)
+        if (p[i]) return false;
+    return true;
+}
+
+// Polynomial::evaluate_fft / evaluate_offset_fft (math/src/fft/polynomial.rs:25-68,74-82)
+int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void *coeffs, size_t n_coeffs, size_t blowup_factor,
+                               size_t domain_size, const void *offset_or_null, void *out, size_t out_capacity_elems,
+                               size_t *out_len) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (!out_len || (n_coeffs && !coeffs)) { set_error("null argument"); return LW_ERR_BAD_ARG; }
+    const size_t eb = lw_hip_field_elem_bytes(field, layout);
+    // Polynomial::new strips trailing zero coefficients (math/src/polynomial/mod.rs:19-31)
+    size_t clen = n_coeffs;
+    while (clen > 0 && elem_is_zero((const unsigned char *)coeffs + (clen - 1) * eb, eb)) clen--;
+    size_t m = clen > domain_size ? clen : domain_size;
+    size_t p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    const size_t len = p2 * blowup_factor;
+    *out_len = len;
+    if (!out) return LW_OK;
+    if (out_capacity_elems < len) { set_error("output capacity %zu < %zu", out_capacity_elems, len); return LW_ERR_BAD_ARG; }
+    if (clen == 0) {   // zero polynomial: len zeros, no transform (:33-35)
+        memset(out, 0, len * eb);
+        return LW_OK;
+    }
+    if (len == 0 || (len & (len - 1))) {   // ops::fft rejects it (math/src/fft/cpu/ops.rs:17-19)
+        set_error("Input length is %zu, which is not a power of two", len);
+        return LW_ERR_INPUT_NOT_POW2;
+    }
+    uint32_t log2n = 0;
+    while (((size_t)1 << log2n) < len) log2n++;
+    if (log2n > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
+
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    rc = ensure_init();
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    if (c.host_io_a.ensure(len * eb) || c.host_io_b.ensure(len * eb)) return LW_ERR_ALLOC;
+    // zero padding happens after scaling in the reference, so padded slots stay zero either way
+    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, len * eb, 0), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, coeffs, clen * eb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, len * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.ntt_calls++;
+    return LW_OK;
+}
+
+// Polynomial::interpolate_fft / interpolate_offset_fft (math/src/fft/polynomial.rs:87-127,159-174)
+int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const void *evals, size_t n, const void *offset_or_null,
+                                  void *out_coeffs, size_t *coeff_len) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (!evals || !out_coeffs) { set_error("null argument"); return LW_ERR_BAD_ARG; }
+    if (n == 0 || (n & (n - 1))) {
+        set_error("Input length is %zu, which is not a power of two", n);
+        return LW_ERR_INPUT_NOT_POW2;
+    }
+    uint32_t log2n = 0;
+    while (((size_t)1 << log2n) < n) log2n++;
+    rc = lw_hip_ntt(field, layout, LW_DIR_INVERSE, evals, out_coeffs, log2n, 1, 0, offset_or_null);
+    if (rc) return rc;
+    if (coeff_len) {
+        const size_t eb = lw_hip_field_elem_bytes(field, layout);
+        size_t clen = n;
+        while (clen > 0 && elem_is_zero((const unsigned char *)out_coeffs + (clen - 1) * eb, eb)) clen--;
+        *coeff_len = clen;
+    }
+    return LW_OK;
+}
+
+int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
+                      void *hip_stream) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (lw_hip_curve_point_bytes(curve) == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
+    auto t0 = std::chrono::steady_clock::now();
+    rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream);
+    c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.msm_calls++;
+    return rc;
+}
+
+int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, const void *points, size_t n_points, void *out_point) {
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    if (pb == 0 || !out_point) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
+    if (n_scalars != n_points) {   // MSMError::LengthMismatch (math/src/msm/pippenger.rs:25-27)
+        set_error("scalars and points have different lengths: %zu vs %zu", n_scalars, n_points);
+        return LW_ERR_LENGTH_MISMATCH;
+    }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t n = n_points;
+    if (n) {
+        if (!scalars || !points) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+        if (c.host_io_a.ensure(n * 32) || c.host_io_b.ensure(n * pb)) return LW_ERR_ALLOC;
+        LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    }
+    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0);
+    c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.msm_calls++;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,503 @@
+// Montgomery prime-field arithmetic for gfx950 (and the host side of the library).
+//
+// Values are the same canonical Montgomery residues the reference stores (R = 2^(64*NUM_LIMBS),
+// math/src/field/fields/montgomery_backed_prime_fields.rs:34-51), so any correct implementation is
+// bit-identical to the reference's `cios_optimized_for_moduli_with_one_spare_bit`
+// (math/src/unsigned_integer/montgomery.rs:86-141).  Here a value lives in registers as N 32-bit limbs,
+// least-significant first: gfx950 has no 64x64 multiply, `v_mad_u64_u32` (32x32+64 -> 64) is the widest
+// integer MAC, so 8x32 (256-bit) / 12x32 (384-bit) limbs are the native shape.
+//
+// Memory layout at the boundary is the reference's: u64 limbs, MOST significant limb first
+// (math/src/unsigned_integer/element.rs:29-37); conversion happens only in load/store.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LW_HD __host__ __device__ __forceinline__
+#else
+#define LW_HD inline
+#endif
+
+namespace lw {
+
+// ---------------------------------------------------------------- field parameter packs
+// p(i), one(i), r2(i): 32-bit limb i (LS first) of the modulus, R mod p, R^2 mod p.  INV = -p^-1 mod 2^32.
+struct Stark252 {   // math/src/field/fields/fft_friendly/stark_252_prime_field.rs:13-24
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xffffffffu;
+    static constexpr uint32_t TWO_ADICITY = 192;
+    LW_HD static constexpr uint32_t p(int i) {
+        constexpr uint32_t t[N] = {0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000011u, 0x08000000u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t one(int i) {
+        constexpr uint32_t t[N] = {0xffffffe1u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xfffffdf0u, 0x07ffffffu};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t t[N] = {0x7e000401u, 0xfffffd73u, 0x330fffffu, 0x00000001u, 0xff6f8000u, 0xffffffffu, 0x5e008810u, 0x07ffd4abu};
+        return t[i];
+    }
+    // TWO_ADIC_PRIMITVE_ROOT_OF_UNITY (canonical), 32-bit limbs LS first
+    LW_HD static constexpr uint32_t root(int i) {
+        constexpr uint32_t t[N] = {0x42f8ef94u, 0x6070024fu, 0xe11a6161u, 0xad187148u, 0x9c8b0fa5u, 0x3f046451u, 0x87529cfau, 0x005282dbu};
+        return t[i];
+    }
+};
+struct Fr381 {      // math/src/elliptic_curve/short_weierstrass/curves/bls12_381/default_types.rs:15-30
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xffffffffu;
+    static constexpr uint32_t TWO_ADICITY = 32;
+    LW_HD static constexpr uint32_t p(int i) {
+        constexpr uint32_t t[N] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t one(int i) {
+        constexpr uint32_t t[N] = {0xfffffffeu, 0x00000001u, 0x00034802u, 0x5884b7fau, 0xecbc4ff5u, 0x998c4fefu, 0xacc5056fu, 0x1824b159u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t t[N] = {0xf3f29c6du, 0xc999e990u, 0x87925c23u, 0x2b6cedcbu, 0x7254398fu, 0x05d31496u, 0x9f59ff11u, 0x0748d9d9u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t root(int i) {
+        constexpr uint32_t t[N] = {0xbb30bbb7u, 0x54cc39d9u, 0xfa78eb2bu, 0xc5e433d6u, 0x349d9b3cu, 0x84dd396cu, 0xa08a499du, 0x2ab00961u};
+        return t[i];
+    }
+};
+struct Fp381 {      // math/src/elliptic_curve/short_weierstrass/curves/bls12_381/field_extension.rs:13-22
+    static constexpr int N = 12;
+    static constexpr uint32_t INV = 0xfffcfffdu;
+    LW_HD static constexpr uint32_t p(int i) {
+        constexpr uint32_t t[N] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u, 0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t one(int i) {
+        constexpr uint32_t t[N] = {0x0002fffdu, 0x76090000u, 0xc40c0002u, 0xebf4000bu, 0x53c758bau, 0x5f489857u, 0x70525745u, 0x77ce5853u, 0xa256ec6du, 0x5c071a97u, 0xfa80e493u, 0x15f65ec3u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t t[N] = {0x1c341746u, 0xf4df1f34u, 0x09d104f1u, 0x0a76e6a6u, 0x4c95b6d5u, 0x8de5476cu, 0x939d83c0u, 0x67eb88a9u, 0xb519952du, 0x9a793e85u, 0x92cae3aau, 0x11988fe5u};
+        return t[i];
+    }
+};
+struct Fp254 {      // math/src/elliptic_curve/short_weierstrass/curves/bn_254/field_extension.rs:15-25
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xe4866389u;
+    LW_HD static constexpr uint32_t p(int i) {
+        constexpr uint32_t t[N] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t one(int i) {
+        constexpr uint32_t t[N] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t t[N] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+        return t[i];
+    }
+};
+
+// ---------------------------------------------------------------- multi-limb element
+template <class F>
+struct Fe {
+    static constexpr int N = F::N;
+    uint32_t v[F::N];
+
+    LW_HD static Fe zero() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = 0;
+        return r;
+    }
+    LW_HD static Fe one() {   // R mod p
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = F::one(i);
+        return r;
+    }
+    LW_HD static Fe r2() {
+        Fe r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.v[i] = F::r2(i);
+        return r;
+    }
+    LW_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= v[i];
+        return o == 0;
+    }
+    LW_HD bool operator==(const Fe &b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= v[i] ^ b.v[i];
+        return o == 0;
+    }
+    LW_HD bool operator!=(const Fe &b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p else a       (a < 2p, all moduli here have a spare top bit)
+template <class F>
+LW_HD Fe<F> reduce_once(const Fe<F> &a) {
+    constexpr int N = F::N;
+    Fe<F> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)a.v[i] - F::p(i) - borrow;
+        d.v[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+
+// IsField::add (montgomery_backed_prime_fields.rs:121-135, spare-bit branch)
+template <class F>
+LW_HD Fe<F> fe_add(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N;
+    Fe<F> s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        s.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return reduce_once<F>(s);
+}
+
+// IsField::sub (:157-163): a - b, + p on borrow
+template <class F>
+LW_HD Fe<F> fe_sub(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N;
+    Fe<F> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
+        d.v[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    uint32_t mask = borrow ? 0xffffffffu : 0u;
+    uint64_t c = 0;
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)d.v[i] + (F::p(i) & mask);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+
+// IsField::neg (:166-172)
+template <class F>
+LW_HD Fe<F> fe_neg(const Fe<F> &a) {
+    constexpr int N = F::N;
+    Fe<F> r;
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) nz |= a.v[i];
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)F::p(i) - a.v[i] - borrow;
+        r.v[i] = nz ? (uint32_t)t : 0u;
+        borrow = (t >> 32) & 1;
+    }
+    return r;
+}
+
+template <class F>
+LW_HD Fe<F> fe_dbl(const Fe<F> &a) { return fe_add<F>(a, a); }
+
+// Montgomery product a*b*R^-1 mod p, canonical in [0,p).
+//
+// Host build: operand-scanning CIOS over 32-bit limbs in plain C++ (used for twiddle seeds, N^-1, the
+// final MSM window combine).
+//
+// Device build (gfx950): product-scanning (FIPS) Montgomery.  Each column sum lives in a 96-bit
+// accumulator (one VGPR pair + one VGPR); every partial product is exactly one `v_mad_u64_u32`
+// (32x32+64 -> 64, carry-out to VCC) followed by one `v_addc_co_u32` into the top word.  Plain C++ makes
+// hipcc materialise zero-extended pairs (3-4 v_mov + a 64-bit add per product), so the MAC chains are
+// inline asm, several MACs per statement (hipcc pads one wait state after every asm statement).
+// Multiplications by the modulus limbs are resolved at compile time: zero limbs vanish, small limbs
+// become inline constants, the rest are SGPR literals (Stark252: p = 2^251 + 17*2^192 + 1, INV = -1).
+template <class F>
+LW_HD Fe<F> fe_mul_portable(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N;
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            c += (uint64_t)a.v[j] * b.v[i] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        uint32_t tN = (uint32_t)c;          // t < 2p < 2^(32N) on row entry (spare top bit), so word N starts at 0
+        uint32_t m = t[0] * F::INV;
+        c = ((uint64_t)m * F::p(0) + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            c += (uint64_t)m * F::p(j) + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += tN;
+        t[N - 1] = (uint32_t)c;             // (t + a*b_i + m*p) / 2^32 < 2p: the high word is 0
+    }
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return reduce_once<F>(r);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LW_MAC_V(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
+
+// acc(96) += a0*b0 [+ a1*b1 ...]; all operands VGPRs
+__device__ __forceinline__ void mac96_x1(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0) {
+    asm(LW_MAC_V("%2", "%3") : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0) : "vcc");
+}
+__device__ __forceinline__ void mac96_x2(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+    asm(LW_MAC_V("%2", "%3") LW_MAC_V("%4", "%5") : "+v"(lo), "+v"(hi) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+}
+__device__ __forceinline__ void mac96_x4(uint64_t &lo, uint32_t &hi, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1,
+                                         uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+    asm(LW_MAC_V("%2", "%3") LW_MAC_V("%4", "%5") LW_MAC_V("%6", "%7") LW_MAC_V("%8", "%9")
+        : "+v"(lo), "+v"(hi)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+        : "vcc");
+}
+// acc(96) += m * C for a compile-time constant C
+template <uint32_t C>
+__device__ __forceinline__ void mac96_c1(uint64_t &lo, uint32_t &hi, uint32_t m0) {
+    if constexpr (C == 0) {
+    } else if constexpr (C <= 64) {
+        asm(LW_MAC_V("%2", "%3") : "+v"(lo), "+v"(hi) : "v"(m0), "n"(C) : "vcc");
+    } else {
+        asm(LW_MAC_V("%2", "%3") : "+v"(lo), "+v"(hi) : "v"(m0), "s"(C) : "vcc");
+    }
+}
+template <uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3>
+__device__ __forceinline__ void mac96_s4(uint64_t &lo, uint32_t &hi, uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3) {
+    asm(LW_MAC_V("%2", "%3") LW_MAC_V("%4", "%5") LW_MAC_V("%6", "%7") LW_MAC_V("%8", "%9")
+        : "+v"(lo), "+v"(hi)
+        : "v"(m0), "s"(C0), "v"(m1), "s"(C1), "v"(m2), "s"(C2), "v"(m3), "s"(C3)
+        : "vcc");
+}
+
+// column K: acc += sum_{i=I}^{IEND-1} a[i]*b[K-i]
+template <class F, int K, int I, int IEND>
+__device__ __forceinline__ void col_ab(uint64_t &lo, uint32_t &hi, const Fe<F> &a, const Fe<F> &b) {
+    if constexpr (I + 4 <= IEND) {
+        mac96_x4(lo, hi, a.v[I], b.v[K - I], a.v[I + 1], b.v[K - I - 1], a.v[I + 2], b.v[K - I - 2], a.v[I + 3], b.v[K - I - 3]);
+        col_ab<F, K, I + 4, IEND>(lo, hi, a, b);
+    } else if constexpr (I + 2 <= IEND) {
+        mac96_x2(lo, hi, a.v[I], b.v[K - I], a.v[I + 1], b.v[K - I - 1]);
+        col_ab<F, K, I + 2, IEND>(lo, hi, a, b);
+    } else if constexpr (I + 1 <= IEND) {
+        mac96_x1(lo, hi, a.v[I], b.v[K - I]);
+    }
+}
+template <uint32_t C>
+constexpr bool lw_is_literal() { return C > 64; }
+// column K: acc += sum_{i=I}^{IEND-1} m[i]*p[K-i]
+template <class F, int K, int I, int IEND>
+__device__ __forceinline__ void col_mp(uint64_t &lo, uint32_t &hi, const uint32_t (&m)[F::N]) {
+    if constexpr (I + 4 <= IEND) {
+        if constexpr (lw_is_literal<F::p(K - I)>() && lw_is_literal<F::p(K - I - 1)>() && lw_is_literal<F::p(K - I - 2)>() &&
+                      lw_is_literal<F::p(K - I - 3)>()) {
+            mac96_s4<F::p(K - I), F::p(K - I - 1), F::p(K - I - 2), F::p(K - I - 3)>(lo, hi, m[I], m[I + 1], m[I + 2], m[I + 3]);
+            col_mp<F, K, I + 4, IEND>(lo, hi, m);
+        } else {
+            mac96_c1<F::p(K - I)>(lo, hi, m[I]);
+            col_mp<F, K, I + 1, IEND>(lo, hi, m);
+        }
+    } else if constexpr (I + 1 <= IEND) {
+        mac96_c1<F::p(K - I)>(lo, hi, m[I]);
+        col_mp<F, K, I + 1, IEND>(lo, hi, m);
+    }
+}
+template <class F, int K>
+__device__ __forceinline__ void fips_col(uint64_t &lo, uint32_t &hi, const Fe<F> &a, const Fe<F> &b, uint32_t (&m)[F::N],
+                                         uint32_t (&t)[F::N]) {
+    constexpr int N = F::N;
+    if constexpr (K < N) {
+        col_ab<F, K, 0, K + 1>(lo, hi, a, b);
+        col_mp<F, K, 0, K>(lo, hi, m);
+        uint32_t mk;
+        if constexpr (F::INV == 0xffffffffu) mk = 0u - (uint32_t)lo;
+        else mk = (uint32_t)lo * F::INV;
+        m[K] = mk;
+        mac96_c1<F::p(0)>(lo, hi, mk);
+    } else {
+        col_ab<F, K, K - N + 1, N>(lo, hi, a, b);
+        col_mp<F, K, K - N + 1, N>(lo, hi, m);
+        t[K - N] = (uint32_t)lo;
+    }
+    lo = (lo >> 32) | ((uint64_t)hi << 32);
+    hi = 0;
+    if constexpr (K + 1 < 2 * N) fips_col<F, K + 1>(lo, hi, a, b, m, t);
+}
+template <class F>
+__device__ __forceinline__ Fe<F> fe_mul_gfx9(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N;
+    uint32_t m[N], t[N];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+    fips_col<F, 0>(lo, hi, a, b, m, t);
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return reduce_once<F>(r);
+}
+#endif
+
+template <class F>
+LW_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_gfx9<F>(a, b);
+#else
+    return fe_mul_portable<F>(a, b);
+#endif
+}
+
+template <class F>
+LW_HD Fe<F> fe_sqr(const Fe<F> &a) { return fe_mul<F>(a, a); }
+
+// x^e for a small exponent, Montgomery domain
+template <class F>
+LW_HD Fe<F> fe_pow_u64(Fe<F> base, uint64_t e) {
+    Fe<F> r = Fe<F>::one();
+    while (e) {
+        if (e & 1) r = fe_mul<F>(r, base);
+        base = fe_sqr<F>(base);
+        e >>= 1;
+    }
+    return r;
+}
+
+// Inverse by Fermat (a^(p-2)); result is the canonical residue, hence bit-identical to the reference's
+// binary-EEA inv (montgomery_backed_prime_fields.rs:175-247).  Off the hot path (a handful per call).
+template <class F>
+LW_HD Fe<F> fe_inv(const Fe<F> &a) {
+    constexpr int N = F::N;
+    uint32_t e[N];
+    // e = p - 2
+    uint64_t borrow = 2;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)F::p(i) - borrow;
+        e[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fe<F> r = Fe<F>::one();
+    for (int i = N - 1; i >= 0; i--) {
+        for (int bit = 31; bit >= 0; bit--) {
+            r = fe_sqr<F>(r);
+            if ((e[i] >> bit) & 1) r = fe_mul<F>(r, a);
+        }
+    }
+    return r;
+}
+
+// to / from Montgomery form (from_base_type :280-282, representative :291-293)
+template <class F>
+LW_HD Fe<F> fe_to_mont(const Fe<F> &a) { return fe_mul<F>(a, Fe<F>::r2()); }
+template <class F>
+LW_HD Fe<F> fe_from_mont(const Fe<F> &a) {
+    Fe<F> o = Fe<F>::zero();
+    o.v[0] = 1;
+    return fe_mul<F>(a, o);
+}
+template <class F>
+LW_HD Fe<F> fe_from_u64(uint64_t x) {
+    Fe<F> o = Fe<F>::zero();
+    o.v[0] = (uint32_t)x;
+    o.v[1] = (uint32_t)(x >> 32);
+    return fe_to_mont<F>(o);
+}
+
+// ---------------------------------------------------------------- boundary layout
+// Reference memory: N/2 u64 limbs, limbs[0] most significant, each u64 native little-endian.
+// As a u32 array m[]: m[2i] = lo32(limb i), m[2i+1] = hi32(limb i).  Internal limb k (LS first) sits at
+// m[2*(N/2-1-k/2) + (k&1)].
+template <class F>
+LW_HD constexpr int mem_index(int k) { return 2 * (F::N / 2 - 1 - k / 2) + (k & 1); }
+
+template <class F>
+LW_HD Fe<F> fe_load(const void *ptr) {
+    constexpr int N = F::N;
+    const uint4 *q = reinterpret_cast<const uint4 *>(ptr);
+    uint32_t m[N];
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) {
+        uint4 x = q[i];
+        m[4 * i + 0] = x.x; m[4 * i + 1] = x.y; m[4 * i + 2] = x.z; m[4 * i + 3] = x.w;
+    }
+    Fe<F> r;
+#pragma unroll
+    for (int k = 0; k < N; k++) r.v[k] = m[mem_index<F>(k)];
+    return r;
+}
+template <class F>
+LW_HD void fe_store(void *ptr, const Fe<F> &a) {
+    constexpr int N = F::N;
+    uint32_t m[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) m[mem_index<F>(k)] = a.v[k];
+    uint4 *q = reinterpret_cast<uint4 *>(ptr);
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) q[i] = make_uint4(m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]);
+}
+
+// ---------------------------------------------------------------- BabyBear (31-bit), R = 2^32 in registers
+// math/src/field/fields/u32_montgomery_backend_prime_field.rs:84-118,273-303
+struct BabyBear {
+    static constexpr uint32_t P = 2013265921u;   // 0x78000001
+    static constexpr uint32_t MU = 0x88000001u;  // +p^-1 mod 2^32 (NOT negated, :33-49)
+    static constexpr uint32_t R2 = 0x45dddde3u;  // 2^64 mod p
+    static constexpr uint32_t ONE = 0x0ffffffeu; // 2^32 mod p
+    static constexpr uint32_t TWO_ADICITY = 24;  // babybear.rs:29 / babybear_u32.rs:17
+    static constexpr uint32_t ROOT = 21;
+};
+
+LW_HD uint32_t bb_reduce(uint64_t x) {   // x * 2^-32 mod p, x < p * 2^32
+    uint32_t t = (uint32_t)x * BabyBear::MU;
+    uint64_t u = (uint64_t)t * BabyBear::P;
+    uint32_t hi = (uint32_t)((x - u) >> 32);
+    return (x < u) ? hi + BabyBear::P : hi;
+}
+LW_HD uint32_t bb_mul(uint32_t a, uint32_t b) { return bb_reduce((uint64_t)a * b); }
+LW_HD uint32_t bb_add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    return s >= BabyBear::P ? s - BabyBear::P : s;
+}
+LW_HD uint32_t bb_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + BabyBear::P - b; }
+LW_HD uint32_t bb_pow(uint32_t a, uint64_t e) {
+    uint32_t r = BabyBear::ONE;
+    while (e) {
+        if (e & 1) r = bb_mul(r, a);
+        a = bb_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+LW_HD uint32_t bb_inv(uint32_t a) { return bb_pow(a, (uint64_t)BabyBear::P - 2); }
+// The reference also keeps BabyBear as MontgomeryBackendPrimeField<_,1> with R = 2^64 (babybear.rs:19-20):
+// memory word = a*2^64 mod p in a u64.  Convert at the boundary: r64 -> r32 is one reduction (x*2^-32),
+// r32 -> r64 is a Montgomery product with 2^64 mod p (x*2^64*2^-32 = x*2^32).
+LW_HD uint32_t bb_from_r64(uint64_t w) { return bb_reduce(w); }            // w < p
+LW_HD uint64_t bb_to_r64(uint32_t v) { return (uint64_t)bb_mul(v, BabyBear::R2); }
+
+}  // namespace lw

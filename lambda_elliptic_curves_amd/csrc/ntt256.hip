@@ -1,0 +1,235 @@
+// Host side of the 256-bit-field NTT: twiddle cache, pass planning, launches.
+#include <vector>
+#include "context.h"
+#include "ntt_kernels.cuh"
+
+namespace lw {
+
+// ---- host field helpers (same limb code as the device, compiled for x86) ----
+template <class F>
+static Fe<F> host_root_of_unity(uint32_t order, bool inverse) {
+    // IsFFTField::get_primitive_root_of_unity (math/src/field/traits.rs:82-94)
+    if (order == 0) return Fe<F>::one();
+    Fe<F> g;
+    for (int i = 0; i < F::N; i++) g.v[i] = F::root(i);
+    g = fe_to_mont<F>(g);
+    for (uint32_t i = 0; i < F::TWO_ADICITY - order; i++) g = fe_sqr<F>(g);
+    if (inverse) g = fe_inv<F>(g);
+    return g;
+}
+
+// lo[i] = base^i (i < 2^hbits), hi[i] = base^(i * 2^hbits) (i < hi_count); internal 32-byte layout
+template <class F>
+static int upload_power_tables(const Fe<F> &base, uint32_t hbits, uint64_t hi_count, DeviceBuf &lo, DeviceBuf &hi) {
+    const uint64_t lo_count = 1ull << hbits;
+    std::vector<uint32_t> hl(lo_count * 8), hh(hi_count * 8);
+    Fe<F> acc = Fe<F>::one();
+    for (uint64_t i = 0; i < lo_count; i++) {
+        for (int k = 0; k < 8; k++) hl[i * 8 + k] = acc.v[k];
+        acc = fe_mul<F>(acc, base);
+    }
+    Fe<F> step = acc;   // base^(2^hbits)
+    acc = Fe<F>::one();
+    for (uint64_t i = 0; i < hi_count; i++) {
+        for (int k = 0; k < 8; k++) hh[i * 8 + k] = acc.v[k];
+        acc = fe_mul<F>(acc, step);
+    }
+    if (lo.ensure(lo_count * 32) || hi.ensure(hi_count * 32)) return LW_ERR_ALLOC;
+    LW_HIP_CHECK(hipMemcpy(lo.p, hl.data(), lo_count * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpy(hi.p, hh.data(), hi_count * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+template <class F>
+static int ensure_twiddles(Context &c, int field, lw_dir_t dir, uint32_t log2n, hipStream_t stream) {
+    TwiddleTable &t = c.tw[field][dir];
+    if (t.valid && t.log_n >= log2n) return LW_OK;
+    if (log2n < 1) return LW_OK;
+    // build for at least 2^16 so small transforms never trigger a rebuild storm
+    uint32_t L = log2n < 16 ? 16 : log2n;
+    if (L > F::TWO_ADICITY) L = log2n;
+    const uint32_t bits = L - 1;
+    const uint64_t count = 1ull << bits;
+    if (t.buf.ensure(count * 32)) return LW_ERR_ALLOC;
+    const uint32_t hbits = (bits + 1) / 2;
+    Fe<F> w = host_root_of_unity<F>(L, dir == LW_DIR_INVERSE);
+    DeviceBuf lo, hi;
+    int rc = upload_power_tables<F>(w, hbits, 1ull << (bits - hbits), lo, hi);
+    if (rc) { lo.release(); hi.release(); return rc; }
+    const uint32_t threads = 256;
+    const uint64_t blocks = (count + threads - 1) / threads;
+    hipLaunchKernelGGL((twiddle_fill_kernel<F>), dim3((uint32_t)blocks), dim3(threads), 0, stream, (uint4 *)t.buf.p,
+                       (const uint4 *)lo.p, (const uint4 *)hi.p, bits, hbits, count);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+    lo.release();
+    hi.release();
+    t.log_n = L;
+    t.valid = true;
+    c.timings.twiddle_bytes = 0;
+    for (int f = 0; f < 3; f++)
+        for (int d = 0; d < 2; d++) c.timings.twiddle_bytes += c.tw[f][d].valid ? c.tw[f][d].buf.bytes : 0;
+    return LW_OK;
+}
+
+// ---- pass planning ----
+struct NttPlan {
+    int npass;
+    uint32_t s0[8], r[8], logC[8];
+};
+
+static NttPlan plan_passes(uint32_t L, uint32_t max_r) {
+    NttPlan pl{};
+    pl.npass = (int)((L + max_r - 1) / max_r);
+    if (pl.npass < 1) pl.npass = 1;
+    uint32_t base = L / pl.npass, extra = L % pl.npass, s = 0;
+    for (int i = 0; i < pl.npass; i++) {
+        uint32_t r = base + ((uint32_t)i < extra ? 1 : 0);
+        pl.s0[i] = s;
+        pl.r[i] = r;
+        uint32_t room = NTT_TILE_LOG - r;
+        uint32_t avail = L - s - r;   // non-last: log2 of the row stride; last: 0 unless multi-pass
+        if (i == pl.npass - 1) avail = L - r;
+        pl.logC[i] = room < avail ? room : avail;
+        s += r;
+    }
+    return pl;
+}
+
+static void split_steps(uint32_t r, NttPassParams &p) {
+    uint32_t nsteps = (r + 2) / 3, left = r;
+    p.nsteps = nsteps;
+    for (uint32_t i = 0; i < nsteps; i++) {
+        uint32_t k = (left + (nsteps - i) - 1) / (nsteps - i);
+        p.k[i] = k;
+        left -= k;
+    }
+}
+
+static uint32_t g_ntt_max_r = 8;
+void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > NTT_TILE_LOG ? NTT_TILE_LOG : r); }
+
+template <class F>
+static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bool invert, const void *d_in,
+                           void *d_out, uint32_t log2n, uint32_t batch, uint64_t in_stride, uint64_t out_stride,
+                           hipStream_t stream) {
+    CosetCache &cc = c.coset[invert ? 1 : 0];
+    const uint32_t hbits = (log2n + 1) / 2;
+    bool hit = cc.valid && cc.field == field && cc.hbits == hbits && cc.inverse == invert;
+    for (int i = 0; i < 8 && hit; i++) hit = cc.words[i] == base_words[i];
+    if (!hit) {
+        Fe<F> b;
+        for (int i = 0; i < 8; i++) b.v[i] = base_words[i];
+        if (b.is_zero()) {
+            set_error("coset offset is zero");
+            return LW_ERR_INV_ZERO;
+        }
+        if (invert) b = fe_inv<F>(b);
+        LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);   // previous users of the cached tables
+        int rc = upload_power_tables<F>(b, hbits, 1ull << (log2n - hbits), cc.lo, cc.hi);
+        if (rc) return rc;
+        cc.valid = true;
+        cc.field = field;
+        cc.hbits = hbits;
+        cc.inverse = invert;
+        for (int i = 0; i < 8; i++) cc.words[i] = base_words[i];
+    }
+    const uint64_t n = 1ull << log2n;
+    const uint32_t threads = 256;
+    dim3 grid((uint32_t)((n + threads - 1) / threads), batch);
+    hipLaunchKernelGGL((scale_powers_kernel<F>), grid, dim3(threads), 0, stream, (const uint4 *)d_in, (uint4 *)d_out,
+                       (const uint4 *)cc.lo.p, (const uint4 *)cc.hi.p, hbits, n, in_stride, out_stride);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+template <class F>
+static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
+                      uint32_t batch, uint64_t stride, const uint32_t *coset_words, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    if (stride == 0) stride = n;
+    if (log2n == 0) {   // N = 1: the transform (and N^-1 = 1, h^0 = 1) is the identity
+        if (d_in != d_out)
+            LW_HIP_CHECK(hipMemcpy2DAsync(d_out, stride * 32, d_in, stride * 32, 32, batch, hipMemcpyDeviceToDevice, stream),
+                         LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+    int rc = ensure_twiddles<F>(c, field, dir, log2n, stream);
+    if (rc) return rc;
+    const uint4 *tw = (const uint4 *)c.tw[field][dir].buf.p;
+
+    NttPlan pl = plan_passes(log2n, g_ntt_max_r);
+    const bool need_scratch = pl.npass > 1 || d_in == d_out || (coset_words && dir == LW_DIR_FORWARD);
+    if (need_scratch && c.scratch.ensure((size_t)n * batch * 32)) return LW_ERR_ALLOC;
+    c.timings.scratch_bytes = c.scratch.bytes;
+
+    const void *src = d_in;
+    uint64_t src_stride = stride;
+    if (coset_words && dir == LW_DIR_FORWARD) {   // c_j * h^j before the transform (evaluate_offset_fft)
+        rc = scale_by_powers<F>(c, field, coset_words, false, d_in, c.scratch.p, log2n, batch, stride, n, stream);
+        if (rc) return rc;
+        src = c.scratch.p;
+        src_stride = n;
+    }
+
+    if (pl.npass == 1 && src == d_out) {
+        // single pass on aliased buffers: the last pass permutes across tiles, so stage the input first
+        LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, n * 32, d_in, stride * 32, n * 32, batch, hipMemcpyDeviceToDevice, stream),
+                     LW_ERR_LAUNCH);
+        src = c.scratch.p;
+        src_stride = n;
+    }
+
+    for (int i = 0; i < pl.npass; i++) {
+        const bool last = (i == pl.npass - 1);
+        NttPassParams p{};
+        p.tw = tw;
+        p.L = log2n;
+        p.s0 = pl.s0[i];
+        p.r = pl.r[i];
+        p.logC = pl.logC[i];
+        split_steps(p.r, p);
+        p.in = (const uint4 *)src;
+        p.in_batch_stride = src_stride;
+        if (last) {
+            if (src == d_out) {
+                set_error("internal: last NTT pass would run in place");
+                return LW_ERR_BAD_ARG;
+            }
+            p.out = (uint4 *)d_out;
+            p.out_batch_stride = stride;
+            if (dir == LW_DIR_INVERSE) {
+                Fe<F> ninv = fe_inv<F>(fe_from_u64<F>(n));   // FieldElement::from(len as u64).inv()
+                p.scale = 1;
+                for (int k = 0; k < 8; k++) p.sc[k] = ninv.v[k];
+            }
+        } else {
+            p.out = (uint4 *)c.scratch.p;
+            p.out_batch_stride = n;
+        }
+        const uint32_t blocks = 1u << (log2n - p.r - p.logC);
+        dim3 grid(blocks, batch);
+        if (last)
+            hipLaunchKernelGGL((ntt_pass_kernel<F, true>), grid, dim3(NTT_THREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((ntt_pass_kernel<F, false>), grid, dim3(NTT_THREADS), 0, stream, p);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        src = p.out;
+        src_stride = p.out_batch_stride;
+    }
+
+    if (coset_words && dir == LW_DIR_INVERSE) {   // interpolate_offset_fft: scale by offset^-i afterwards
+        rc = scale_by_powers<F>(c, field, coset_words, true, d_out, d_out, log2n, batch, stride, stride, stream);
+        if (rc) return rc;
+    }
+    return LW_OK;
+}
+
+int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
+                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream) {
+    if (field == LW_FIELD_STARK252)
+        return ntt256_run<Stark252>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream);
+    return ntt256_run<Fr381>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream);
+}
+
+}  // namespace lw

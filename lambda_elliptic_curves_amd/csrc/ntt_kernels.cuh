@@ -1,0 +1,240 @@
+// Radix-2 NTT passes for 256-bit Montgomery fields (Stark252, BLS12-381 Fr) on gfx950.
+//
+// Dataflow = the reference's NR decimation-in-time transform (math/src/fft/cpu/fft.rs:20-55) followed by
+// the bit-reverse permutation (math/src/fft/cpu/bit_reversing.rs:2-18): stage s pairs elements N/2^(s+1)
+// apart and group g uses twiddle T[g] = w^bitrev(g) (math/src/fft/cpu/roots_of_unity.rs:26-45).  Because
+// every field op returns the canonical residue, results are byte-identical to the reference however
+// the stages are scheduled; here they are scheduled for the GPU:
+//
+//   * log2(N) stages are cut into passes of r <= 11 stages.  One workgroup owns a tile of 2^r "rows"
+//     (the index bits the pass's stages touch) x C adjacent "columns" (contiguous elements), stages it in
+//     LDS once and runs all r stages there: a pass costs one HBM read + one HBM write of the vector,
+//     versus one round trip per stage in the reference's CUDA path (math/src/fft/gpu/cuda/ops.rs:28-38).
+//   * inside a pass a work-item keeps 2^k (k <= 3) elements in VGPRs and runs k stages register-only
+//     (radix-8 = 12 Montgomery products per 8 elements), exchanging through LDS between groups of k stages.
+//   * the last pass folds the bit-reverse permutation into its store addresses: a workgroup takes the C
+//     tiles whose bit-reversed tile ids are consecutive, so natural-order output leaves as C*32-byte runs.
+//   * the INTT's N^-1 scaling (math/src/fft/polynomial.rs:172-173) is fused into the last pass.
+#pragma once
+#include "field.cuh"
+
+namespace lw {
+
+constexpr int NTT_TILE_LOG = 11;              // 2048 elements x 32 B = 64 KiB of LDS per workgroup
+constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
+constexpr int NTT_THREADS = 256;
+
+struct NttPassParams {
+    const uint4 *in;       // element e = in[2e], in[2e+1] (reference memory layout)
+    uint4 *out;
+    const uint4 *tw;       // bit-reversed twiddle table, internal layout (8 x u32, LS limb first)
+    uint64_t in_batch_stride;   // elements between consecutive transforms of a batch
+    uint64_t out_batch_stride;
+    uint32_t L;            // log2 N
+    uint32_t s0;           // first stage of this pass
+    uint32_t r;            // stages in this pass
+    uint32_t logC;         // log2 columns per tile
+    uint32_t nsteps;
+    uint32_t k[4];         // stages per register step, sum = r
+    uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
+    uint32_t sc[8];
+};
+
+__device__ __forceinline__ uint32_t bitrev_bits(uint32_t x, uint32_t bits) {
+    return bits ? (__brev(x) >> (32 - bits)) : 0u;
+}
+
+template <class F>
+__device__ __forceinline__ Fe<F> tw_load(const uint4 *tw, uint64_t g) {
+    uint4 a = tw[2 * g], b = tw[2 * g + 1];
+    Fe<F> r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void tw_store(uint4 *tw, uint64_t g, const Fe<F> &x) {
+    tw[2 * g] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    tw[2 * g + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// element in reference memory layout (two 16-byte halves) <-> limbs; pure register renaming
+template <class F>
+__device__ __forceinline__ Fe<F> unpack_mem(uint4 q0, uint4 q1) {
+    Fe<F> r;
+    r.v[6] = q0.x; r.v[7] = q0.y; r.v[4] = q0.z; r.v[5] = q0.w;
+    r.v[2] = q1.x; r.v[3] = q1.y; r.v[0] = q1.z; r.v[1] = q1.w;
+    return r;
+}
+template <class F>
+__device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
+    q0 = make_uint4(a.v[6], a.v[7], a.v[4], a.v[5]);
+    q1 = make_uint4(a.v[2], a.v[3], a.v[0], a.v[1]);
+}
+
+// One work-item: 2^K elements, K stages in registers.
+template <class F, int K, bool LAST>
+__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[NTT_TILE], const uint4 *gin,
+                                         uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
+                                         uint32_t hi_uniform, uint32_t hi_low, bool last_step) {
+    constexpr int E = 1 << K;
+    const uint32_t r = p.r, logC = p.logC, L = p.L;
+    const uint32_t sh = r - t0 - K;
+    uint32_t c, mr;
+    if (LAST && step == 0) {           // rows fastest: global loads run along contiguous rows
+        mr = w & ((1u << (r - K)) - 1);
+        c = w >> (r - K);
+    } else {                           // columns fastest
+        c = w & ((1u << logC) - 1);
+        mr = w >> logC;
+    }
+    const uint32_t m_low = mr & ((1u << sh) - 1);
+    const uint32_t m_high = mr >> sh;
+    const uint32_t mbase = (m_high << (sh + K)) | m_low;
+    uint32_t hi_c = hi_uniform;
+    uint64_t gbase = base;
+    if (LAST) {
+        hi_c = (bitrev_bits(c, logC) << (L - r - logC)) | hi_low;
+        gbase = (uint64_t)hi_c << r;
+    }
+
+    Fe<F> x[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        uint32_t m = mbase | ((uint32_t)j << sh);
+        uint4 q0, q1;
+        if (step == 0) {
+            uint64_t g = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
+            q0 = gin[2 * g];
+            q1 = gin[2 * g + 1];
+        } else {
+            uint32_t idx = (m << logC) | c;
+            q0 = lds[0][idx];
+            q1 = lds[1][idx];
+        }
+        x[j] = unpack_mem<F>(q0, q1);
+    }
+
+    // stage u of this step == stage s0 + t0 + u of the transform
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int half = 1 << (K - 1 - u);
+        const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
+#pragma unroll
+        for (int jt = 0; jt < (1 << u); jt++) {
+            Fe<F> tw = tw_load<F>(p.tw, gt | (uint32_t)jt);
+#pragma unroll
+            for (int jl = 0; jl < half; jl++) {
+                const int j = (jt << (K - u)) | jl;
+                Fe<F> wb = fe_mul<F>(tw, x[j + half]);
+                Fe<F> a = x[j];
+                x[j] = fe_add<F>(a, wb);
+                x[j + half] = fe_sub<F>(a, wb);
+                __builtin_amdgcn_sched_barrier(0);   // keep butterflies serial: 4 interleaved products cost >250 VGPRs
+            }
+        }
+    }
+
+    if (last_step && p.scale) {
+        Fe<F> sc;
+#pragma unroll
+        for (int i = 0; i < 8; i++) sc.v[i] = p.sc[i];
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = fe_mul<F>(x[j], sc);
+    }
+
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        uint32_t m = mbase | ((uint32_t)j << sh);
+        uint32_t idx = (m << logC) | c;
+        uint4 q0, q1;
+        pack_mem<F>(x[j], q0, q1);
+        lds[0][idx] = q0;
+        lds[1][idx] = q1;
+    }
+}
+
+template <class F, bool LAST>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) {
+    __shared__ uint4 lds[2][NTT_TILE];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = p.r, logC = p.logC, L = p.L;
+    const uint32_t tile_log = r + logC;
+    const uint4 *gin = p.in + 2 * (uint64_t)blockIdx.y * p.in_batch_stride;
+    uint4 *gout = p.out + 2 * (uint64_t)blockIdx.y * p.out_batch_stride;
+    const uint32_t b = blockIdx.x;
+
+    uint64_t base = 0;
+    uint32_t lgS = 0, hi_uniform = 0, hi_low = 0;
+    if (!LAST) {
+        lgS = L - p.s0 - r;                       // log2 of the row stride
+        const uint32_t lo_bits = lgS - logC;      // column blocks per `hi`
+        const uint32_t lo_blk = b & ((1u << lo_bits) - 1);
+        hi_uniform = b >> lo_bits;
+        base = ((uint64_t)hi_uniform << (L - p.s0)) + ((uint64_t)lo_blk << logC);
+    } else {
+        hi_low = bitrev_bits(b, L - r - logC);
+    }
+
+    uint32_t t0 = 0;
+    for (uint32_t step = 0; step < p.nsteps; step++) {
+        const uint32_t k = p.k[step];
+        const uint32_t nitems = 1u << (tile_log - k);
+        const bool last_step = (step + 1 == p.nsteps);
+        if (step) __syncthreads();
+        for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
+            if (k == 3) ntt_item<F, 3, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) ntt_item<F, 2, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else ntt_item<F, 1, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+        }
+        t0 += k;
+    }
+    __syncthreads();
+
+    // coalesced write-out: two lanes per element, 16 B each
+    const uint32_t total = 2u << tile_log;
+    for (uint32_t f = tid; f < total; f += NTT_THREADS) {
+        const uint32_t e = f >> 1, plane = f & 1;
+        const uint32_t c = e & ((1u << logC) - 1);
+        const uint32_t m = e >> logC;
+        uint64_t g;
+        if (!LAST) g = base + ((uint64_t)m << lgS) + c;
+        else g = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)b << logC) + c;
+        gout[2 * g + plane] = lds[plane][e];
+    }
+}
+
+// T[g] = w^bitrev_{bits}(g), from two small power tables: w^e = lo[e & mask] * hi[e >> hbits]
+template <class F>
+__global__ void twiddle_fill_kernel(uint4 *tw, const uint4 *lo, const uint4 *hi, uint32_t bits, uint32_t hbits,
+                                    uint64_t count) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    uint32_t e = bitrev_bits((uint32_t)g, bits);
+    Fe<F> a = tw_load<F>(lo, e & ((1u << hbits) - 1));
+    Fe<F> b = tw_load<F>(hi, e >> hbits);
+    tw_store<F>(tw, g, fe_mul<F>(a, b));
+}
+
+// x[i] *= h^i  (Polynomial::scale, math/src/polynomial/mod.rs:259-271), h^i = lo[i & mask] * hi[i >> hbits];
+// optional extra constant factor (used to fold N^-1 when it was not fused elsewhere)
+template <class F>
+__global__ void scale_powers_kernel(const uint4 *in, uint4 *out, const uint4 *lo, const uint4 *hi, uint32_t hbits,
+                                    uint64_t n, uint64_t in_batch_stride, uint64_t out_batch_stride) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *gin = in + 2 * (uint64_t)blockIdx.y * in_batch_stride;
+    uint4 *gout = out + 2 * (uint64_t)blockIdx.y * out_batch_stride;
+    Fe<F> a = tw_load<F>(lo, i & ((1ull << hbits) - 1));
+    Fe<F> b = tw_load<F>(hi, i >> hbits);
+    Fe<F> pw = fe_mul<F>(a, b);
+    Fe<F> x = unpack_mem<F>(gin[2 * i], gin[2 * i + 1]);
+    x = fe_mul<F>(x, pw);
+    uint4 q0, q1;
+    pack_mem<F>(x, q0, q1);
+    gout[2 * i] = q0;
+    gout[2 * i + 1] = q1;
+}
+
+}  // namespace lw

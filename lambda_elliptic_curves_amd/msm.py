@@ -1,0 +1,45 @@
+"""Host-side mirror of math/src/msm/pippenger.rs `msm` for the HIP backend."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .errors import check
+
+
+class Curve:
+    def __init__(self, name, curve, coord_words):
+        self.name, self.curve, self.coord_words = name, curve, coord_words
+        self.point_words = 3 * coord_words
+
+    def __repr__(self):
+        return f"Curve({self.name})"
+
+
+BLS12381Curve = Curve("BLS12381Curve", L.CURVE_BLS12_381_G1, 6)
+BN254Curve = Curve("BN254Curve", L.CURVE_BN254_G1, 4)
+BN254TwistCurve = Curve("BN254TwistCurve", L.CURVE_BN254_G2, 8)
+BLS12381TwistCurve = Curve("BLS12381TwistCurve", L.CURVE_BLS12_381_G2, 12)
+
+
+def msm(curve, cs, points):
+    """pippenger::msm(cs, points): cs = (n,4) uint64 canonical scalars (MS limb first), points = (n, 3*coord_words)
+    uint64 projective points.  Returns one projective point; only its affine image is canonical.
+    Different lengths -> LengthMismatch (pippenger.rs:25-27); empty input -> neutral element."""
+    s = np.ascontiguousarray(cs, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, curve.point_words)
+    out = np.zeros(curve.point_words, dtype=np.uint64)
+    check(L.lib().lw_hip_msm(curve.curve, s.ctypes.data_as(C.c_void_p), s.shape[0], p.ctypes.data_as(C.c_void_p),
+                             p.shape[0], out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def msm_device(curve, t_scalars, t_points, n, stream=None):
+    """Device-resident MSM on torch tensors; returns the projective result as a numpy array."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    out = np.zeros(curve.point_words, dtype=np.uint64)
+    check(L.lib().lw_hip_msm_device(curve.curve, C.c_void_p(t_scalars.data_ptr()), C.c_void_p(t_points.data_ptr()), n,
+                                    out.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+    return out

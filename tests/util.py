@@ -1,0 +1,42 @@
+"""Shared helpers for the parity tests: seeded inputs in the reference's memory layout."""
+import numpy as np
+
+from oracle import oracle as O
+
+# (product Field, oracle field id)
+def field_pairs():
+    from lambda_elliptic_curves_amd import fft
+    return {
+        "stark252": (fft.Stark252PrimeField, O.F_STARK252),
+        "fr381": (fft.FrField, O.F_FR381),
+        "babybear_u64": (fft.Babybear31PrimeField, O.F_BABYBEAR_U64),
+        "babybear_u32": (fft.Babybear31PrimeFieldU32, O.F_BABYBEAR_U32),
+        "babybear_ext4": (fft.Degree4BabyBearExtensionField, O.F_BABYBEAR_EXT4),
+    }
+
+
+P_BABYBEAR = 2013265921
+
+
+def rand_elems(name, n, seed):
+    """n canonical residues (any value < p is a valid Montgomery-form element), reference layout."""
+    rng = np.random.default_rng(seed)
+    if name in ("stark252", "fr381"):
+        a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+        top_bits = 59 if name == "stark252" else 62      # 2^251 < p_stark, 2^254 < p_fr381
+        a[:, 0] &= np.uint64((1 << top_bits) - 1)
+        return a
+    if name == "babybear_u32":
+        return rng.integers(0, P_BABYBEAR, size=n, dtype=np.uint32)
+    if name == "babybear_u64":
+        return rng.integers(0, P_BABYBEAR, size=n, dtype=np.uint64)
+    if name == "babybear_ext4":
+        return rng.integers(0, P_BABYBEAR, size=(n, 4), dtype=np.uint64)
+    raise KeyError(name)
+
+
+def offset_elem(name, h):
+    """Coset offset h (small canonical int) as one domain-field element in memory form."""
+    base = {"babybear_ext4": "babybear_u64"}.get(name, name)
+    oid = field_pairs()[base][1]
+    return O.elems_to_mont(oid, [h])[0] if oid != O.F_BABYBEAR_U32 else O.elems_to_mont(oid, [h])[:1]
