@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X NTT + MSM hot path (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
+  * NTT leg (the `value`): one forward Stark252 NTT of 2^log2n elements (Polynomial::evaluate_fft backend arm),
+  * MSM leg (reported under "msm"): one BLS12-381 G1 Pippenger MSM of 2^msm_log2n points.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the units are independent transforms / point
+sets, one per rank (STARK columns / SRS shards) — weak scaling, no data-path collective
+for the NTT leg; the MSM leg combines the per-rank partial sums with one all_gather of a single point.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def rand_field_elems(n, seed, top_bits=59):
+    """Synthetic field elements: uniformly random canonical residues < 2^251 < p."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    a[:, 0] &= np.uint64((1 << top_bits) - 1)
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=24, help="NTT size (Stark252)")
+    ap.add_argument("--msm-log2n", type=int, default=20, help="MSM size (BLS12-381 G1)")
+    ap.add_argument("--workload", choices=["ntt", "msm", "all"], default="all")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-log2n", type=int, default=24, help="CPU baseline sample size")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from lambda_elliptic_curves_amd import _lib, fft, msm
+    import ctypes as C
+    dev = C.c_int(local_rank)
+    rc = _lib.lib().lw_hip_init(C.byref(dev), 1)
+    if rc:
+        raise RuntimeError(_lib.last_error())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    result = {}
+    # ------------------------------------------------------------------ NTT leg
+    if args.workload in ("ntt", "all"):
+        L = args.log2n
+        n = 1 << L
+        fld = fft.Stark252PrimeField
+        host = rand_field_elems(n, 0x5EED0000 + L + 1000 * rank)
+        t_in = torch.from_numpy(host.view(np.int64)).cuda()
+        t_out = torch.empty_like(t_in)
+        del host
+        for _ in range(args.warmup):
+            fft.ntt_device(fld, t_in, t_out, L)
+        barrier()
+        _lib.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fft.ntt_device(fld, t_in, t_out, L)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof = _lib.profile_end()
+        dt = max_over_ranks(dt)
+        ms_per_step = dt * 1e3 / args.steps
+        value = world * n * args.steps / dt
+        # dominant kernel = the LDS-tiled NTT pass (all passes of one transform are launches of it)
+        launches = sum(v[0] for k, v in prof.items() if k.startswith("ntt_pass_kernel"))
+        total_ms = sum(v[1] for k, v in prof.items() if k.startswith("ntt_pass_kernel"))
+        passes = launches // max(args.steps, 1)
+        avg_launch_ms = total_ms / max(launches, 1)
+        alg_bytes_per_launch = 2.0 * n * 32 / max(passes, 1)     # 2*N*B per transform, spread over its passes
+        achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        traffic_src = None
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("log2n") == L:
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = tj.get("source")
+            except Exception:
+                pass
+        result.update({
+            "metric": "NTT elems/sec (Stark252 radix-2, 2^%d, forward, bit-exact vs CPU) [+ MSM G1 point-adds/sec under 'msm']" % L,
+            "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (256-bit Montgomery, 32-bit limbs)", "data": "synthetic",
+            "config": {"workload": "Stark252 NTT 2^%d forward, 1 transform per GPU, inputs resident in HBM" % L,
+                       "field": "Stark252", "log2n": L, "passes": passes, "parallelism": "independent transforms per rank"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "ntt_pass_kernel", "avg_launch_ms": avg_launch_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "note": "256-bit NTT is integer-VALU bound (see 'valu'); HBM fraction reported as required"},
+            "valu": {"modmul_per_s": (n // 2) * L * args.steps * world / dt, "unit": "Montgomery products/s",
+                     "peak_measured": 182.5e9, "peak_source": "profiles/r01_microbench.txt (fe_mul Stark252, all CUs)"},
+            "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
+        })
+        del t_in, t_out
+        torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ MSM leg
+    if args.workload in ("msm", "all"):
+        try:
+            from bench_msm import run_msm_leg   # added with the MSM kernels
+            result["msm"] = run_msm_leg(args, world, rank, barrier, max_over_ranks)
+        except ImportError:
+            result["msm"] = None
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("ntt", "all"):
+        from oracle import oracle as O   # checker / baseline only — never on the product path
+        Lc = args.cpu_log2n
+        a = rand_field_elems(1 << Lc, 0x5EED0000 + Lc)
+        t0 = time.perf_counter()
+        O.evaluate_fft(O.F_STARK252, a)
+        dtc = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": (1 << Lc) / dtc, "unit": "elements/s", "cores": 1, "kind": "port",
+                                  "sample": "one Stark252 evaluate_fft of 2^%d elements, oracle/lw_oracle.c (C restatement of the "
+                                            "reference's single-threaded CPU path, twiddles regenerated per call), %.1f s" % (Lc, dtc),
+                                  "host_cores_available": os.cpu_count()}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

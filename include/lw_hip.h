@@ -84,12 +84,27 @@ typedef struct {
     uint64_t scratch_bytes;
 } lw_timings_t;
 
+/* Per-kernel device timing (HIP events recorded on the launch stream around every kernel this library
+ * launches between begin and end).  Instrumentation only; the reference's analogue is the `instruments`
+ * feature's per-round timers (provers/stark/src/prover.rs:884-1049). */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} lw_kernel_time_t;
+typedef struct {
+    int n;
+    lw_kernel_time_t k[16];
+} lw_profile_t;
+
 /* ---- context ---- */
 int lw_hip_init(const int *device_ids, int n_devices); /* NULL,0 -> current device */
 void lw_hip_shutdown(void);
 int lw_hip_device_count(void);
 const char *lw_hip_last_error(void);
 int lw_hip_get_timings(lw_timings_t *out);
+int lw_hip_profile_begin(void);             /* start recording kernel events */
+int lw_hip_profile_end(lw_profile_t *out);  /* synchronise, stop, report */
 size_t lw_hip_field_elem_bytes(lw_field_t field, lw_layout_t layout);
 size_t lw_hip_curve_point_bytes(lw_curve_t curve);
 

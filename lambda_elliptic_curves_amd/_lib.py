@@ -19,6 +19,7 @@ CURVE_BLS12_381_G1, CURVE_BN254_G1, CURVE_BN254_G2, CURVE_BLS12_381_G2 = 0, 1, 2
 
 EXPORTS = [
     "lw_hip_init", "lw_hip_shutdown", "lw_hip_device_count", "lw_hip_last_error", "lw_hip_get_timings",
+    "lw_hip_profile_begin", "lw_hip_profile_end",
     "lw_hip_field_elem_bytes", "lw_hip_curve_point_bytes", "lw_hip_ntt", "lw_hip_ntt_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
 ]
@@ -27,6 +28,14 @@ EXPORTS = [
 class Timings(C.Structure):
     _fields_ = [("last_ntt_ms", C.c_double), ("last_msm_ms", C.c_double), ("ntt_calls", C.c_uint64),
                 ("msm_calls", C.c_uint64), ("twiddle_bytes", C.c_uint64), ("scratch_bytes", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("n", C.c_int), ("k", KernelTime * 16)]
 
 
 _lib = None
@@ -56,6 +65,9 @@ def lib():
     L.lw_hip_device_count.restype = i
     L.lw_hip_last_error.restype = C.c_char_p
     L.lw_hip_get_timings.argtypes = [C.POINTER(Timings)]
+    L.lw_hip_profile_begin.restype = i
+    L.lw_hip_profile_end.argtypes = [C.POINTER(Profile)]
+    L.lw_hip_profile_end.restype = i
     L.lw_hip_field_elem_bytes.argtypes = [i, i]
     L.lw_hip_field_elem_bytes.restype = sz
     L.lw_hip_curve_point_bytes.argtypes = [i]
@@ -74,6 +86,21 @@ def lib():
     L.lw_hip_msm_device.restype = i
     _lib = L
     return L
+
+
+def profile_begin():
+    rc = lib().lw_hip_profile_begin()
+    if rc:
+        raise RuntimeError(f"lw_hip_profile_begin: [{rc}] {last_error()}")
+
+
+def profile_end():
+    """-> {kernel name: (launches, total_ms)} measured with HIP events on the launch stream."""
+    p = Profile()
+    rc = lib().lw_hip_profile_end(C.byref(p))
+    if rc:
+        raise RuntimeError(f"lw_hip_profile_end: [{rc}] {last_error()}")
+    return {p.k[j].name.decode(): (int(p.k[j].launches), float(p.k[j].total_ms)) for j in range(p.n)}
 
 
 def last_error():

@@ -43,6 +43,23 @@ void DeviceBuf::release() {
     bytes = 0;
 }
 
+hipEvent_t Context::prof_begin(hipStream_t s) {
+    if (!profiling) return nullptr;
+    hipEvent_t e = nullptr;
+    if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    (void)hipEventRecord(e, s);
+    return e;
+}
+void Context::prof_end(const char *name, hipEvent_t e0, hipStream_t s) {
+    if (!profiling || !e0) return;
+    hipEvent_t e1 = nullptr;
+    if (!event_pool.empty()) { e1 = event_pool.back(); event_pool.pop_back(); }
+    else if (hipEventCreate(&e1) != hipSuccess) return;
+    (void)hipEventRecord(e1, s);
+    spans.push_back(ProfSpan{name, e0, e1});
+}
+
 Context &ctx() {
     static Context c;
     return c;
@@ -195,6 +212,44 @@ int lw_hip_device_count(void) {
 }
 
 const char *lw_hip_last_error(void) { return g_last_error.c_str(); }
+
+int lw_hip_profile_begin(void) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    c.spans.clear();
+    c.profiling = true;
+    return LW_OK;
+}
+
+int lw_hip_profile_end(lw_profile_t *out) {
+    if (!out) return LW_ERR_BAD_ARG;
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.profiling = false;
+    memset(out, 0, sizeof(*out));
+    LW_HIP_CHECK(hipDeviceSynchronize(), LW_ERR_LAUNCH);
+    for (auto &sp : c.spans) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, sp.e0, sp.e1);
+        int idx = -1;
+        for (int i = 0; i < out->n; i++)
+            if (strcmp(out->k[i].name, sp.name) == 0) idx = i;
+        if (idx < 0 && out->n < 16) {
+            idx = out->n++;
+            strncpy(out->k[idx].name, sp.name, sizeof(out->k[idx].name) - 1);
+        }
+        if (idx >= 0) {
+            out->k[idx].launches++;
+            out->k[idx].total_ms += ms;
+        }
+        c.event_pool.push_back(sp.e0);
+        c.event_pool.push_back(sp.e1);
+    }
+    c.spans.clear();
+    return LW_OK;
+}
 
 int lw_hip_get_timings(lw_timings_t *out) {
     if (!out) return LW_ERR_BAD_ARG;

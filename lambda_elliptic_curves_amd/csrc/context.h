@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/lw_hip.h"
 
 namespace lw {
@@ -45,7 +46,19 @@ struct CosetCache {
     bool valid = false;
 };
 
+struct ProfSpan {
+    const char *name;
+    hipEvent_t e0, e1;
+};
+
 struct Context {
+    bool profiling = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    // record a begin/end event pair around one kernel launch when profiling
+    hipEvent_t prof_begin(hipStream_t s);
+    void prof_end(const char *name, hipEvent_t e0, hipStream_t s);
+
     bool initialised = false;
     int device = -1;
     std::mutex mu;

@@ -137,8 +137,10 @@ static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bo
     const uint64_t n = 1ull << log2n;
     const uint32_t threads = 256;
     dim3 grid((uint32_t)((n + threads - 1) / threads), batch);
+    hipEvent_t pe = c.prof_begin(stream);
     hipLaunchKernelGGL((scale_powers_kernel<F>), grid, dim3(threads), 0, stream, (const uint4 *)d_in, (uint4 *)d_out,
                        (const uint4 *)cc.lo.p, (const uint4 *)cc.hi.p, hbits, n, in_stride, out_stride);
+    c.prof_end("scale_powers_kernel", pe, stream);
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     return LW_OK;
 }
@@ -209,10 +211,12 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         }
         const uint32_t blocks = 1u << (log2n - p.r - p.logC);
         dim3 grid(blocks, batch);
+        hipEvent_t pe = c.prof_begin(stream);
         if (last)
             hipLaunchKernelGGL((ntt_pass_kernel<F, true>), grid, dim3(NTT_THREADS), 0, stream, p);
         else
             hipLaunchKernelGGL((ntt_pass_kernel<F, false>), grid, dim3(NTT_THREADS), 0, stream, p);
+        c.prof_end(last ? "ntt_pass_kernel<last>" : "ntt_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;
         src_stride = p.out_batch_stride;
