@@ -1,0 +1,222 @@
+// Short-Weierstrass (a = 0) group law in homogeneous projective coordinates for the four groups in scope.
+//
+// The reference's operate_with (math/src/elliptic_curve/short_weierstrass/point.rs:171-207) branches on the
+// exceptional cases (P+P, P+(-P), identity).  A bucket accumulation of a structured SRS can hit all of them, and
+// divergent branches cost a whole wavefront, so the device uses the COMPLETE addition law of Renes-Costello-
+// Batina (Eurocrypt 2016, Alg. 7/9 for a = 0): one straight-line formula, valid for every pair of inputs
+// including the identity (0:1:0), on curves without rational 2-torsion (all four groups have odd order).
+// The group element computed is the same; only the projective representative differs, and the reference
+// itself defines point equality up to scaling (math/src/elliptic_curve/point.rs:57-63).
+#pragma once
+#include "field.cuh"
+
+namespace lw {
+
+// ---------------------------------------------------------------- base-field op packs
+template <class F>
+struct FpOps {
+    using T = Fe<F>;
+    static constexpr int WORDS32 = F::N;
+    LW_HD static T add(const T &a, const T &b) { return fe_add<F>(a, b); }
+    LW_HD static T sub(const T &a, const T &b) { return fe_sub<F>(a, b); }
+    LW_HD static T mul(const T &a, const T &b) { return fe_mul<F>(a, b); }
+    LW_HD static T sqr(const T &a) { return fe_sqr<F>(a); }
+    LW_HD static T neg(const T &a) { return fe_neg<F>(a); }
+    LW_HD static T dbl(const T &a) { return fe_add<F>(a, a); }
+    LW_HD static T zero() { return T::zero(); }
+    LW_HD static T one() { return T::one(); }
+    LW_HD static bool is_zero(const T &a) { return a.is_zero(); }
+    LW_HD static bool eq(const T &a, const T &b) { return a == b; }
+    LW_HD static T inv(const T &a) { return fe_inv<F>(a); }
+    // reference memory (N/2 u64, MS limb first) <-> limbs
+    LW_HD static T load(const void *p) { return fe_load<F>(p); }
+    LW_HD static void store(void *p, const T &a) { fe_store<F>(p, a); }
+    static constexpr int BYTES = F::N * 4;
+};
+
+// Fp2 = Fp[u]/(u^2+1); element stored as [c0, c1] (bls12_381/field_extension.rs:29, bn_254/field_extension.rs:36).
+// Karatsuba product for both towers: the result is the same field element as the reference's schoolbook
+// BN254 product (bn_254/field_extension.rs:47-49).
+template <class F>
+struct Fp2 {
+    Fe<F> c0, c1;
+};
+template <class F>
+struct Fp2Ops {
+    using T = Fp2<F>;
+    static constexpr int WORDS32 = 2 * F::N;
+    LW_HD static T add(const T &a, const T &b) { return T{fe_add<F>(a.c0, b.c0), fe_add<F>(a.c1, b.c1)}; }
+    LW_HD static T sub(const T &a, const T &b) { return T{fe_sub<F>(a.c0, b.c0), fe_sub<F>(a.c1, b.c1)}; }
+    LW_HD static T mul(const T &a, const T &b) {
+        Fe<F> a0b0 = fe_mul<F>(a.c0, b.c0);
+        Fe<F> a1b1 = fe_mul<F>(a.c1, b.c1);
+        Fe<F> z = fe_mul<F>(fe_add<F>(a.c0, a.c1), fe_add<F>(b.c0, b.c1));
+        return T{fe_sub<F>(a0b0, a1b1), fe_sub<F>(fe_sub<F>(z, a0b0), a1b1)};
+    }
+    LW_HD static T sqr(const T &a) {
+        Fe<F> v0 = fe_mul<F>(a.c0, a.c1);
+        Fe<F> c0 = fe_mul<F>(fe_add<F>(a.c0, a.c1), fe_sub<F>(a.c0, a.c1));
+        return T{c0, fe_add<F>(v0, v0)};
+    }
+    LW_HD static T neg(const T &a) { return T{fe_neg<F>(a.c0), fe_neg<F>(a.c1)}; }
+    LW_HD static T dbl(const T &a) { return add(a, a); }
+    LW_HD static T zero() { return T{Fe<F>::zero(), Fe<F>::zero()}; }
+    LW_HD static T one() { return T{Fe<F>::one(), Fe<F>::zero()}; }
+    LW_HD static bool is_zero(const T &a) { return a.c0.is_zero() && a.c1.is_zero(); }
+    LW_HD static bool eq(const T &a, const T &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
+    LW_HD static T inv(const T &a) {
+        Fe<F> n = fe_inv<F>(fe_add<F>(fe_sqr<F>(a.c0), fe_sqr<F>(a.c1)));
+        return T{fe_mul<F>(a.c0, n), fe_mul<F>(fe_neg<F>(a.c1), n)};
+    }
+    LW_HD static T load(const void *p) {
+        return T{fe_load<F>(p), fe_load<F>((const char *)p + F::N * 4)};
+    }
+    LW_HD static void store(void *p, const T &a) {
+        fe_store<F>(p, a.c0);
+        fe_store<F>((char *)p + F::N * 4, a.c1);
+    }
+    static constexpr int BYTES = 2 * F::N * 4;
+};
+
+// ---------------------------------------------------------------- curves (b3 = 3*b)
+struct Bls12381G1 {   // y^2 = x^3 + 4   (bls12_381/curve.rs:38-46)
+    using B = FpOps<Fp381>;
+    LW_HD static B::T mul_b3(const B::T &x) {   // 12x
+        B::T x4 = B::dbl(B::dbl(x));
+        return B::add(B::dbl(x4), x4);
+    }
+};
+struct Bn254G1 {      // y^2 = x^3 + 3   (bn_254/curve.rs:32-40)
+    using B = FpOps<Fp254>;
+    LW_HD static B::T mul_b3(const B::T &x) {   // 9x
+        return B::add(B::dbl(B::dbl(B::dbl(x))), x);
+    }
+};
+struct Bls12381G2 {   // y^2 = x^3 + 4(1+u)   (bls12_381/twist.rs:40-48)
+    using B = Fp2Ops<Fp381>;
+    LW_HD static B::T mul_b3(const B::T &x) {   // 12(1+u) * (x0 + x1 u) = 12(x0 - x1) + 12(x0 + x1) u
+        Fe<Fp381> d = fe_sub<Fp381>(x.c0, x.c1), s = fe_add<Fp381>(x.c0, x.c1);
+        Fe<Fp381> d4 = fe_dbl<Fp381>(fe_dbl<Fp381>(d)), s4 = fe_dbl<Fp381>(fe_dbl<Fp381>(s));
+        return B::T{fe_add<Fp381>(fe_dbl<Fp381>(d4), d4), fe_add<Fp381>(fe_dbl<Fp381>(s4), s4)};
+    }
+};
+struct Bn254G2 {      // y^2 = x^3 + 3/(9+u)   (bn_254/twist.rs:46-61); 3b' precomputed, Montgomery form
+    using B = Fp2Ops<Fp254>;
+    LW_HD static constexpr uint32_t b3c0(int i) {
+        constexpr uint32_t t[8] = {0xb62e0d6au, 0x3baa927cu, 0xd1b664fdu, 0xd71e7c52u, 0xd95d4664u, 0x03873e63u, 0x082ab8f4u, 0x0e75b5b1u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t b3c1(int i) {
+        constexpr uint32_t t[8] = {0x7596fe35u, 0xaab7c666u, 0xbb6a27bau, 0x31d21a78u, 0x680401ffu, 0x85dd7297u, 0xdf39a7e9u, 0x03c52d6au};
+        return t[i];
+    }
+    LW_HD static B::T mul_b3(const B::T &x) {
+        B::T k;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { k.c0.v[i] = b3c0(i); k.c1.v[i] = b3c1(i); }
+        return B::mul(x, k);
+    }
+};
+
+// ---------------------------------------------------------------- points
+template <class C>
+struct Point {
+    typename C::B::T x, y, z;
+};
+
+template <class C>
+LW_HD Point<C> pt_identity() {   // (0 : 1 : 0)  (short_weierstrass/point.rs:156-162)
+    using B = typename C::B;
+    return Point<C>{B::zero(), B::one(), B::zero()};
+}
+template <class C>
+LW_HD bool pt_is_identity(const Point<C> &p) { return C::B::is_zero(p.z); }
+
+// Reference memory layout: X, Y, Z consecutive (elliptic_curve/point.rs:8-10)
+template <class C>
+LW_HD Point<C> pt_load(const void *p) {
+    using B = typename C::B;
+    const char *c = (const char *)p;
+    return Point<C>{B::load(c), B::load(c + B::BYTES), B::load(c + 2 * B::BYTES)};
+}
+template <class C>
+LW_HD void pt_store(void *p, const Point<C> &a) {
+    using B = typename C::B;
+    char *c = (char *)p;
+    B::store(c, a.x);
+    B::store(c + B::BYTES, a.y);
+    B::store(c + 2 * B::BYTES, a.z);
+}
+
+// Complete addition, RCB16 Algorithm 7 (a = 0): 12M + 2 m_3b + 19a
+template <class C>
+LW_HD Point<C> pt_add(const Point<C> &p, const Point<C> &q) {
+    using B = typename C::B;
+    using T = typename B::T;
+    T t0 = B::mul(p.x, q.x);
+    T t1 = B::mul(p.y, q.y);
+    T t2 = B::mul(p.z, q.z);
+    T t3 = B::mul(B::add(p.x, p.y), B::add(q.x, q.y));
+    T t4 = B::add(t0, t1);
+    t3 = B::sub(t3, t4);
+    t4 = B::mul(B::add(p.y, p.z), B::add(q.y, q.z));
+    T x3 = B::add(t1, t2);
+    t4 = B::sub(t4, x3);
+    x3 = B::mul(B::add(p.x, p.z), B::add(q.x, q.z));
+    T y3 = B::add(t0, t2);
+    y3 = B::sub(x3, y3);
+    x3 = B::add(t0, t0);
+    t0 = B::add(x3, t0);
+    t2 = C::mul_b3(t2);
+    T z3 = B::add(t1, t2);
+    t1 = B::sub(t1, t2);
+    y3 = C::mul_b3(y3);
+    x3 = B::mul(t4, y3);
+    t2 = B::mul(t3, t1);
+    x3 = B::sub(t2, x3);
+    y3 = B::mul(y3, t0);
+    t1 = B::mul(t1, z3);
+    y3 = B::add(t1, y3);
+    t0 = B::mul(t0, t3);
+    z3 = B::mul(z3, t4);
+    z3 = B::add(z3, t0);
+    return Point<C>{x3, y3, z3};
+}
+
+// Complete doubling, RCB16 Algorithm 9 (a = 0): 6M + 2S + 1 m_3b
+template <class C>
+LW_HD Point<C> pt_dbl(const Point<C> &p) {
+    using B = typename C::B;
+    using T = typename B::T;
+    T t0 = B::sqr(p.y);
+    T z3 = B::dbl(B::dbl(B::dbl(t0)));
+    T t1 = B::mul(p.y, p.z);
+    T t2 = B::sqr(p.z);
+    t2 = C::mul_b3(t2);
+    T x3 = B::mul(t2, z3);
+    T y3 = B::add(t0, t2);
+    z3 = B::mul(t1, z3);
+    t1 = B::dbl(t2);
+    t2 = B::add(t1, t2);
+    t0 = B::sub(t0, t2);
+    y3 = B::mul(t0, y3);
+    y3 = B::add(x3, y3);
+    t1 = B::mul(p.x, p.y);
+    x3 = B::mul(t0, t1);
+    x3 = B::dbl(x3);
+    return Point<C>{x3, y3, z3};
+}
+
+template <class C>
+LW_HD Point<C> pt_neg(const Point<C> &p) { return Point<C>{p.x, C::B::neg(p.y), p.z}; }
+
+// (x/z : y/z : 1), identity -> (0:1:0)   (elliptic_curve/point.rs:41-54)
+template <class C>
+LW_HD Point<C> pt_to_affine(const Point<C> &p) {
+    using B = typename C::B;
+    if (B::is_zero(p.z)) return pt_identity<C>();
+    typename B::T zi = B::inv(p.z);
+    return Point<C>{B::mul(p.x, zi), B::mul(p.y, zi), B::one()};
+}
+
+}  // namespace lw

@@ -1,0 +1,131 @@
+// Pippenger multi-scalar multiplication on gfx950: sum_i k_i * P_i  (math/src/msm/pippenger.rs:18-103).
+//
+// The reference walks windows sequentially, adding each point into one of 2^c - 1 buckets and folding the
+// buckets with a running sum (pippenger.rs:69-101).  The group element computed here is the same; the
+// schedule is rebuilt for a GPU:
+//   1. digits      every scalar is cut into W = ceil(256/c) unsigned c-bit digits (pippenger.rs:76-77);
+//                  (window, digit) is a bucket key; digit 0 contributes nothing (:78).
+//   2. scatter     counting sort of point indices by key: histogram -> exclusive scan -> scatter
+//                  (all windows in one pass; the order inside a bucket is irrelevant to the group sum).
+//   3. accumulate  segmented reduction over each bucket's index list: every work-item sums <= CH points of
+//                  ONE bucket with the complete addition law (ec.cuh); buckets longer than CH are reduced in
+//                  further rounds, so a skewed scalar distribution (all scalars equal) costs extra rounds,
+//                  not one serial thread.
+//   4. bucket reduce  sum_d d*B[d] per window by a hierarchical running sum: groups of g buckets give
+//                  (A_j, Q_j) = (sum B[d], sum (d-d0) B[d]); then sum_d d*B[d] = sum_j Q_j + g * sum_j j*A_j,
+//                  the second term being the same problem on n/g points.
+//   5. combine     the <= 64 window sums are folded most-significant first, acc <- 2^c * acc + S_w
+//                  (pippenger.rs:101), on the host with the same limb code, and normalised to (x/z : y/z : 1).
+#include "msm_core.cuh"
+
+namespace lw {
+
+// ---------------------------------------------------------------- digits / sort
+__device__ __forceinline__ uint32_t scalar_word(const uint32_t *s, int j) {   // 32-bit word j, LS first
+    return s[2 * (3 - j / 2) + (j & 1)];
+}
+__device__ __forceinline__ uint32_t scalar_digit(const uint32_t *s, uint32_t w, uint32_t c) {
+    const uint32_t o = w * c, j = o >> 5, sh = o & 31;
+    uint64_t v = scalar_word(s, j);
+    if (j + 1 < 8) v |= (uint64_t)scalar_word(s, j + 1) << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+__global__ void msm_hist_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
+    uint4 a = q[0], b = q[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t d = scalar_digit(s, w, c);
+        if (d) atomicAdd(&cnt[(w << c) + d], 1u);
+    }
+}
+
+__global__ void msm_scatter_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off,
+                                   uint32_t *cursor, uint32_t *sorted) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
+    uint4 a = q[0], b = q[1];
+    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+    for (uint32_t w = 0; w < W; w++) {
+        uint32_t d = scalar_digit(s, w, c);
+        if (d) {
+            uint32_t key = (w << c) + d;
+            uint32_t pos = off[key] + atomicAdd(&cursor[key], 1u);
+            sorted[pos] = (uint32_t)i;
+        }
+    }
+}
+
+// Single-workgroup scan.  mode 0: in = counts[K]            -> out[K+1] = exclusive scan(counts)
+//                         mode 1: in = segment offsets[K+1] -> out[K+1] = exclusive scan(ceil(len/CH))
+// *maxlen receives the largest count / segment length seen.
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *in, uint32_t *out, uint32_t K, int mode,
+                                                        uint32_t *maxlen) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t pmax[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (K + 1023) / 1024;
+    const uint32_t b = tid * per, e = min(K, b + per);
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t k = b; k < e; k++) {
+        uint32_t len = mode ? (in[k + 1] - in[k]) : in[k];
+        mx = max(mx, len);
+        sum += mode ? (len + MSM_CH - 1) / MSM_CH : len;
+    }
+    part[tid] = sum;
+    pmax[tid] = mx;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        uint32_t m = tid >= d ? pmax[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        pmax[tid] = max(pmax[tid], m);
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's segment
+    for (uint32_t k = b; k < e; k++) {
+        uint32_t len = mode ? (in[k + 1] - in[k]) : in[k];
+        out[k] = run;
+        run += mode ? (len + MSM_CH - 1) / MSM_CH : len;
+    }
+    if (tid == 1023) {
+        out[K] = part[1023];
+        *maxlen = pmax[1023];
+    }
+}
+
+void msm_launch_hist(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt, hipStream_t s) {
+    hipLaunchKernelGGL(msm_hist_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, scalars, n, c, W, cnt);
+}
+void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off, uint32_t *cursor,
+                        uint32_t *sorted, hipStream_t s) {
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, scalars, n, c, W, off, cursor, sorted);
+}
+void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, hipStream_t s) {
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, s, in, out, K, mode, maxlen);
+}
+
+int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
+int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
+int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
+int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
+
+int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
+               hipStream_t stream) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host);
+        case LW_CURVE_BN254_G1: return msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host);
+        case LW_CURVE_BN254_G2: return msm_run_bn254_g2(c, stream, d_scalars, d_points, n, out_host);
+        case LW_CURVE_BLS12_381_G2: return msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host);
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace lw

@@ -1,0 +1,264 @@
+// Curve-generic part of the Pippenger MSM (see msm.hip for the schedule); instantiated once per curve in its own
+// translation unit so the four groups compile in parallel.
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "context.h"
+#include "ec.cuh"
+
+namespace lw {
+
+constexpr uint32_t MSM_CH = 64;        // points per accumulate work-item
+constexpr uint32_t MSM_G_LOG = 6;      // buckets per running-sum group (2^6)
+constexpr int MSM_THREADS = 128;
+
+// host launchers for the curve-independent kernels (defined in msm.hip)
+void msm_launch_hist(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt, hipStream_t s);
+void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off, uint32_t *cursor,
+                        uint32_t *sorted, hipStream_t s);
+void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, hipStream_t s);
+
+// ---------------------------------------------------------------- accumulate
+// Work-item t sums <= CH items of ONE key.
+//   out_off != nullptr: t is a (key, piece) pair found by binary search in out_off; result -> pout[t]
+//   out_off == nullptr: last round, every key has <= CH items; t is the key; result (identity when the key is
+//                       empty) -> pout[key], the dense bucket array.
+// from_index: items are point indices into the caller's point array (reference layout); otherwise they are
+// partial sums of the previous round (internal layout).
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const void *points, const uint32_t *sorted,
+                                                                      const Point<C> *pin, const uint32_t *seg_off,
+                                                                      const uint32_t *out_off, uint32_t K,
+                                                                      uint32_t total_items, Point<C> *pout, int from_index) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_items) return;
+    uint32_t b, e;
+    if (out_off) {
+        uint32_t lo = 0, hi = K;   // largest key with out_off[key] <= t
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (out_off[mid] <= t) lo = mid; else hi = mid;
+        }
+        b = seg_off[lo] + (t - out_off[lo]) * MSM_CH;
+        e = min(seg_off[lo + 1], b + MSM_CH);
+    } else {
+        b = seg_off[t];
+        e = seg_off[t + 1];
+    }
+    constexpr size_t PB = 3 * C::B::BYTES;
+    Point<C> acc = pt_identity<C>();
+    if (b < e) {
+        if (from_index) acc = pt_load<C>((const char *)points + (size_t)sorted[b] * PB);
+        else acc = pin[b];
+    }
+#pragma nounroll
+    for (uint32_t i = b + 1; i < e; i++) {
+        Point<C> p;
+        if (from_index) p = pt_load<C>((const char *)points + (size_t)sorted[i] * PB);
+        else p = pin[i];
+        acc = pt_add<C>(acc, p);
+    }
+    pout[t] = acc;
+}
+
+// ---------------------------------------------------------------- bucket reduce
+// in: W arrays of n points.  Group j of window w covers d in [j*g, (j+1)*g):
+//   A[w][j] = sum in[d],  Q[w][j] = sum (d - j*g) * in[d]     (running sum from the top, pippenger.rs:85-98)
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const Point<C> *in, uint32_t n, uint32_t g,
+                                                                     uint32_t ngroups, Point<C> *A, Point<C> *Q) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ngroups) return;
+    const uint32_t w = blockIdx.y;
+    const Point<C> *base = in + (size_t)w * n;
+    const uint32_t d0 = j * g, d1 = min(n, d0 + g);
+    Point<C> running = pt_identity<C>(), q = pt_identity<C>();
+#pragma nounroll
+    for (uint32_t d = d1; d-- > d0;) {
+        q = pt_add<C>(q, running);
+        running = pt_add<C>(running, base[d]);
+    }
+    A[(size_t)w * ngroups + j] = running;
+    Q[(size_t)w * ngroups + j] = q;
+}
+
+// S[w] = SQ[w] + 2^k * S1[w]
+template <class C>
+__global__ void msm_combine_kernel(const Point<C> *SQ, const Point<C> *S1, uint32_t k, uint32_t W, Point<C> *S) {
+    uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    Point<C> x = S1[w];
+#pragma nounroll
+    for (uint32_t i = 0; i < k; i++) x = pt_dbl<C>(x);
+    S[w] = pt_add<C>(SQ[w], x);
+}
+
+// ---------------------------------------------------------------- host orchestration
+struct Carver {   // bump allocator over the context workspace
+    char *base;
+    size_t cap, used = 0;
+    void *take(size_t bytes) {
+        used = (used + 255) & ~(size_t)255;
+        void *p = base ? base + used : nullptr;
+        used += bytes;
+        return p;
+    }
+};
+
+static uint32_t pick_window(size_t n) {
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return (uint32_t)c;
+}
+
+template <class C>
+struct MsmRunner {
+    Context &c;
+    hipStream_t stream;
+    uint32_t W;
+
+    // returns device arrays S (sum d*in[d]) and A (sum in[d]), one point per window; temporaries from `cv`
+    int reduce(const Point<C> *in, uint32_t n, Carver &cv, Point<C> **S_out, Point<C> **A_out) {
+        const uint32_t g = 1u << MSM_G_LOG;
+        if (n <= g) {
+            Point<C> *A = (Point<C> *)cv.take(sizeof(Point<C>) * W), *Q = (Point<C> *)cv.take(sizeof(Point<C>) * W);
+            if (cv.base) {
+                hipEvent_t pe = c.prof_begin(stream);
+                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, W), dim3(64), 0, stream, in, n, n, 1u, A, Q);
+                c.prof_end("msm_group_sum_kernel", pe, stream);
+            }
+            *S_out = Q;
+            *A_out = A;
+            return LW_OK;
+        }
+        const uint32_t ng = (n + g - 1) / g;
+        Point<C> *A1 = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)W * ng);
+        Point<C> *Q1 = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)W * ng);
+        if (cv.base) {
+            hipEvent_t pe = c.prof_begin(stream);
+            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((ng + MSM_THREADS - 1) / MSM_THREADS, W), dim3(MSM_THREADS), 0,
+                               stream, in, n, g, ng, A1, Q1);
+            c.prof_end("msm_group_sum_kernel", pe, stream);
+        }
+        Point<C> *S1, *Atot, *Sq_unused, *SQ;
+        int rc = reduce(A1, ng, cv, &S1, &Atot);
+        if (rc) return rc;
+        rc = reduce(Q1, ng, cv, &Sq_unused, &SQ);
+        if (rc) return rc;
+        Point<C> *S = (Point<C> *)cv.take(sizeof(Point<C>) * W);
+        if (cv.base) {
+            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((W + 63) / 64), dim3(64), 0, stream, SQ, S1, MSM_G_LOG, W, S);
+        }
+        *S_out = S;
+        *A_out = Atot;
+        return LW_OK;
+    }
+
+    // one pass over the pipeline; with cv.base == nullptr it only measures the workspace
+    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, Point<C> **S_out,
+                 uint32_t maxlen_hint) {
+        const uint32_t K = W << cbits;
+        const bool dry = cv.base == nullptr;
+        uint32_t *cnt = (uint32_t *)cv.take(4 * (size_t)(K + 1));
+        uint32_t *cursor = (uint32_t *)cv.take(4 * (size_t)(K + 1));
+        uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
+        uint32_t *maxlen_d = (uint32_t *)cv.take(256);
+        uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
+        uint32_t maxlen = maxlen_hint;
+        if (!dry) {
+            LW_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * (size_t)(K + 1) + 512, stream), LW_ERR_LAUNCH);   // cnt + cursor
+            hipEvent_t pe = c.prof_begin(stream);
+            msm_launch_hist(d_scalars, (uint64_t)n, cbits, W, cnt, stream);
+            c.prof_end("msm_hist_kernel", pe, stream);
+            msm_launch_scan(cnt, off, K, 0, maxlen_d, stream);
+            pe = c.prof_begin(stream);
+            msm_launch_scatter(d_scalars, (uint64_t)n, cbits, W, off, cursor, sorted, stream);
+            c.prof_end("msm_scatter_kernel", pe, stream);
+            LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+        }
+        // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
+        const uint32_t *seg = off;
+        const Point<C> *pin = nullptr;
+        bool from_index = true;
+        uint64_t len = maxlen;             // longest segment
+        uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
+        while (len > MSM_CH) {
+            uint32_t *out_off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
+            uint64_t out_bound = items_bound / MSM_CH + K;
+            Point<C> *pout = (Point<C> *)cv.take(sizeof(Point<C>) * out_bound);
+            if (!dry) {
+                msm_launch_scan(seg, out_off, K, 1, maxlen_d, stream);
+                uint32_t total = 0;
+                LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+                LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+                if (total > out_bound) {
+                    set_error("internal: MSM partial count %u exceeds bound %llu", total, (unsigned long long)out_bound);
+                    return LW_ERR_LAUNCH;
+                }
+                if (total) {
+                    const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
+                    hipEvent_t pe = c.prof_begin(stream);
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin,
+                                       seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
+                    c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
+                }
+            }
+            seg = out_off;
+            pin = pout;
+            from_index = false;
+            len = (len + MSM_CH - 1) / MSM_CH;
+            items_bound = out_bound;
+        }
+        Point<C> *buckets = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)K);
+        if (!dry) {
+            const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
+            hipEvent_t pe = c.prof_begin(stream);
+            hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin, seg,
+                               (const uint32_t *)nullptr, K, K, buckets, from_index ? 1 : 0);
+            c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
+        }
+        Point<C> *A_unused;
+        return reduce(buckets, 1u << cbits, cv, S_out, &A_unused);
+    }
+
+    int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {
+        Point<C> result = pt_identity<C>();
+        if (n > 0) {
+            if (n >> 32) {
+                set_error("MSM of %zu points: index width is 32 bits", n);
+                return LW_ERR_BAD_ARG;
+            }
+            const uint32_t cbits = pick_window(n);
+            W = (256 + cbits - 1) / cbits;
+            // size the workspace for the worst case (one bucket holding every point)
+            Carver dry{nullptr, 0};
+            Point<C> *S_d = nullptr;
+            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, (uint32_t)std::min<size_t>(n, 0xffffffffu));
+            if (rc) return rc;
+            if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
+            Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};
+            rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, 0);
+            if (rc) return rc;
+            LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+            std::vector<Point<C>> S(W);
+            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, sizeof(Point<C>) * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+            // fold windows most-significant first: acc <- 2^c * acc + S_w  (pippenger.rs:101)
+            result = S[W - 1];
+            for (uint32_t w = W - 1; w-- > 0;) {
+                for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
+                result = pt_add<C>(result, S[w]);
+            }
+        }
+        result = pt_to_affine<C>(result);
+        pt_store<C>(out_host, result);
+        return LW_OK;
+    }
+};
+
+
+}  // namespace lw

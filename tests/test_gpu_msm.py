@@ -1,0 +1,133 @@
+"""GPU parity: HIP Pippenger MSM (through the C ABI) vs the CPU oracle's restatement of msm::pippenger::msm.
+Equality is on the canonical affine image, as the reference's own PartialEq is up to projective scaling
+(math/src/elliptic_curve/point.rs:57-63).  Mirrors math/src/msm/pippenger.rs:204-233."""
+import numpy as np
+import pytest
+
+from oracle import bigint_def as D
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bls12_381_g1", "bn254_g1", "bn254_g2", "bls12_381_g2"]
+
+
+def aff(oid, p):
+    return O.point_to_affine_ints(oid, p)
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 30, 100, 1000])
+def test_msm_matches_reference_algorithm_small(name, n):
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 100 + n)
+    got = msm.msm(crv, scalars, points)
+    exp = O.msm(oid, scalars, points)
+    assert aff(oid, got) == aff(oid, exp)
+    assert O.ec_eq(oid, got, exp)               # the reference's own equality
+    # output is normalised: Z == 1 (Montgomery one)
+    w = crv.coord_words
+    bf = O.CURVE_BASE_FIELD[oid]
+    assert O.limbs_to_int(got[2 * w:2 * w + O.FIELD_WORDS[bf]]) == O.field_params(bf)["one"]
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 1 << 12), ("bls12_381_g1", 1 << 16), ("bn254_g1", 1 << 14),
+                                    ("bn254_g2", 1 << 11), ("bls12_381_g2", 1 << 10)])
+def test_msm_matches_reference_algorithm_medium(name, n):
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 7 + n)
+    got = msm.msm(crv, scalars, points)
+    exp = O.parallel_msm_with(oid, scalars, points, max(2, O.optimum_window_size(n)), 16)
+    assert aff(oid, got) == aff(oid, exp)
+
+
+def test_msm_vs_affine_bigint_definition():
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    cd = D.BLS12_381_G1
+    rng = np.random.default_rng(3)
+    mult = [int(x) for x in rng.integers(1, 1 << 40, size=20)]
+    g = util.generator(oid)
+    pts = np.stack([O.ec_mul(oid, g, m, 1) for m in mult])
+    ks = [int.from_bytes(rng.bytes(32), "big") for _ in mult]
+    got = msm.msm(crv, O.ints_to_array(ks, 4), pts)
+    total = sum(k * m for k, m in zip(ks, mult))
+    assert aff(oid, got) == cd.tup(cd.mul(total, cd.gen))
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_g1"])
+def test_msm_edge_cases(name):
+    from lambda_elliptic_curves_amd import errors, msm
+    crv, oid = util.curve_pairs()[name]
+    g = util.generator(oid)
+    neutral = O.ec_neutral(oid)
+    # empty input -> neutral element (pippenger.rs:102)
+    out = msm.msm(crv, np.zeros((0, 4), np.uint64), np.zeros((0, crv.point_words), np.uint64))
+    assert aff(oid, out) is None and np.array_equal(out, neutral)
+    with pytest.raises(errors.LengthMismatch):      # pippenger.rs:25-27
+        msm.msm(crv, np.zeros((2, 4), np.uint64), np.stack([g]))
+    r = D.P_FR381 if name == "bls12_381_g1" else D.P_FR254
+    p = O.ec_mul(oid, g, 12345, 1)
+    # duplicates, P and -P in one bucket, identity inputs, zero scalars, scalar = r-1, scalar = 2^256-1
+    pts = np.stack([p, p, O.ec_neg(oid, p), neutral, g, g, p])
+    ks = [7, 7, 7, 99, r - 1, 0, (1 << 256) - 1]
+    got = msm.msm(crv, O.ints_to_array(ks, 4), pts)
+    exp = O.msm(oid, O.ints_to_array(ks, 4), pts)
+    assert aff(oid, got) == aff(oid, exp)
+    # everything cancels -> neutral
+    pts = np.stack([p, O.ec_neg(oid, p)])
+    got = msm.msm(crv, O.ints_to_array([5, 5], 4), pts)
+    assert aff(oid, got) is None
+
+
+def test_msm_skewed_scalars_all_equal():
+    # every point lands in the same bucket of every window: the segmented reduction needs extra rounds
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 20000
+    _, points = util.msm_case(oid, n, 5)
+    k = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef
+    scalars = np.tile(O.int_to_limbs(k, 4), (n, 1))
+    got = msm.msm(crv, scalars, points)
+    acc = O.ec_neutral(oid)          # sum of points, then one scalar multiplication
+    for i in range(n):
+        acc = O.ec_add(oid, acc, points[i])
+    assert aff(oid, got) == aff(oid, O.ec_mul(oid, acc, k))
+    # all points equal, distinct scalars (P+P doubling inside every bucket chain)
+    n2 = 3000
+    scalars2, _ = util.msm_case(oid, n2, 6)
+    pts2 = np.tile(points[0], (n2, 1))
+    got2 = msm.msm(crv, scalars2, pts2)
+    tot = sum(O.array_to_ints(scalars2))
+    assert aff(oid, got2) == aff(oid, O.ec_mul(oid, points[0], tot, 5))
+
+
+def test_msm_device_resident_large_linearity():
+    # 2^20 points: MSM(k, P) + MSM(k', P) == MSM(k + k', P) (size-independent property)
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 1 << 20
+    s1, points = util.msm_case(oid, n, 11)
+    rng = np.random.default_rng(13)
+    s2 = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    s1[:, 0] &= np.uint64((1 << 62) - 1)      # keep k + k' < 2^256
+    ssum = np.zeros_like(s1)
+    carry = np.zeros(n, dtype=np.uint64)
+    for limb in (3, 2, 1, 0):
+        a, b = s1[:, limb], s2[:, limb]
+        t = a + b
+        c1 = (t < a).astype(np.uint64)
+        t2 = t + carry
+        c2 = (t2 < t).astype(np.uint64)
+        ssum[:, limb] = t2
+        carry = c1 + c2
+    tp = torch.from_numpy(points.view(np.int64)).cuda()
+    outs = []
+    for s in (s1, s2, ssum):
+        ts = torch.from_numpy(s.view(np.int64)).cuda()
+        outs.append(msm.msm_device(crv, ts, tp, n))
+    lhs = O.ec_add(oid, outs[0], outs[1])
+    assert aff(oid, lhs) == aff(oid, outs[2])

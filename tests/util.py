@@ -40,3 +40,30 @@ def offset_elem(name, h):
     base = {"babybear_ext4": "babybear_u64"}.get(name, name)
     oid = field_pairs()[base][1]
     return O.elems_to_mont(oid, [h])[0] if oid != O.F_BABYBEAR_U32 else O.elems_to_mont(oid, [h])[:1]
+
+
+def curve_pairs():
+    from lambda_elliptic_curves_amd import msm
+    return {
+        "bls12_381_g1": (msm.BLS12381Curve, O.C_BLS12_381_G1),
+        "bn254_g1": (msm.BN254Curve, O.C_BN254_G1),
+        "bn254_g2": (msm.BN254TwistCurve, O.C_BN254_G2),
+        "bls12_381_g2": (msm.BLS12381TwistCurve, O.C_BLS12_381_G2),
+    }
+
+
+def generator(oid):
+    from oracle import bigint_def as D
+    c = D.CURVES[oid]
+    return O.point_from_affine_ints(oid, c.gen[0].tup(), c.gen[1].tup())
+
+
+def msm_case(oid, n, seed):
+    """Synthetic MSM input: uniform 256-bit canonical scalars, SRS-like projective points
+    P_i = [s0 + i*delta]G built by repeated projective addition (so Z != 1), from a fixed seed."""
+    rng = np.random.default_rng(seed)
+    scalars = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    s0 = int(rng.integers(1, 1 << 62))
+    delta = int(rng.integers(1, 1 << 62))
+    points = O.gen_points(oid, generator(oid), s0, delta, n)
+    return scalars, points

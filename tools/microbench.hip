@@ -174,6 +174,17 @@ int main() {
         printf("RATE mac96 (mad+addc)   %8.2f Gmac/s\n", lanes * iters * 8 / ms / 1e6);
     }
     {
+        // dependent-chain issue: one MAC chain per lane (the shape of one FIPS column), by waves per SIMD
+        for (int wps : {1, 2, 3, 4, 6, 8}) {
+            const int blk = cus * wps;   // 256-thread blocks: 4 waves -> one per SIMD
+            const double ln = (double)blk * 256;
+            float ms = time_ms([&] { hipLaunchKernelGGL((k_mac96<1>), dim3(blk), dim3(256), 0, 0, buf, iters * 4, 1u); });
+            float ms2 = time_ms([&] { hipLaunchKernelGGL((k_mac96<2>), dim3(blk), dim3(256), 0, 0, buf, iters * 2, 1u); });
+            printf("RATE mac96 dependent chain, %d waves/SIMD: ILP1 %8.2f Gmac/s   ILP2 %8.2f Gmac/s\n", wps, ln * iters * 4 / ms / 1e6,
+                   ln * iters * 2 * 2 / ms2 / 1e6);
+        }
+    }
+    {
         const int it2 = 512;
         float ms;
 #define FEMUL(F, NAME)                                                                                         \
