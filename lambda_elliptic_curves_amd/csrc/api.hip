@@ -1,5 +1,6 @@
 // extern "C" boundary (include/lw_hip.h) + context implementation.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <chrono>
 #include <vector>
@@ -65,7 +66,14 @@ Context &ctx() {
     return c;
 }
 
+void ntt_set_max_pass_stages(uint32_t r);
+void ntt_set_config(int cfg);
+void ntt_set_debug(uint32_t d);
+
 static int init_locked(Context &c, const int *device_ids, int n_devices) {
+    if (const char *e = getenv("LW_HIP_NTT_CFG")) ntt_set_config(atoi(e));
+    if (const char *e = getenv("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));
+    if (const char *e = getenv("LW_HIP_NTT_MAX_R")) ntt_set_max_pass_stages((uint32_t)atoi(e));
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {

@@ -19,8 +19,18 @@ struct FpOps {
     static constexpr int WORDS32 = F::N;
     LW_HD static T add(const T &a, const T &b) { return fe_add<F>(a, b); }
     LW_HD static T sub(const T &a, const T &b) { return fe_sub<F>(a, b); }
-    LW_HD static T mul(const T &a, const T &b) { return fe_mul<F>(a, b); }
-    LW_HD static T sqr(const T &a) { return fe_sqr<F>(a); }
+    // A point addition holds ~10 field elements live; letting hipcc interleave its independent products
+    // (for ILP) pushes a 384-bit kernel past 256 VGPRs.  Pinning the products in program order keeps the
+    // live set near its minimum so 2-3 waves fit per SIMD, which is what hides the MAC-chain latency
+    // (profiles/r01_microbench.txt: dependent chains reach 72 % of the MAC rate at 3 waves/SIMD).
+    LW_HD static T mul(const T &a, const T &b) {
+        T r = fe_mul<F>(a, b);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        return r;
+    }
+    LW_HD static T sqr(const T &a) { return mul(a, a); }
     LW_HD static T neg(const T &a) { return fe_neg<F>(a); }
     LW_HD static T dbl(const T &a) { return fe_add<F>(a, a); }
     LW_HD static T zero() { return T::zero(); }

@@ -9,7 +9,7 @@
 namespace lw {
 
 constexpr uint32_t MSM_CH = 64;        // points per accumulate work-item
-constexpr uint32_t MSM_G_LOG = 6;      // buckets per running-sum group (2^6)
+constexpr uint32_t MSM_G_LOG = 4;      // buckets per running-sum group (2^4): short dependent chains, many groups
 constexpr int MSM_THREADS = 128;
 
 // host launchers for the curve-independent kernels (defined in msm.hip)
@@ -62,11 +62,13 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const void 
 }
 
 // ---------------------------------------------------------------- bucket reduce
-// in: W arrays of n points.  Group j of window w covers d in [j*g, (j+1)*g):
+// in: nwin arrays of n points.  Group j of array w covers d in [j*g, (j+1)*g):
 //   A[w][j] = sum in[d],  Q[w][j] = sum (d - j*g) * in[d]     (running sum from the top, pippenger.rs:85-98)
+// out is laid out [2*nwin][ngroups]: rows 0..nwin-1 hold A, rows nwin..2*nwin-1 hold Q, so the next level
+// reduces both families in one launch.
 template <class C>
 __global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const Point<C> *in, uint32_t n, uint32_t g,
-                                                                     uint32_t ngroups, Point<C> *A, Point<C> *Q) {
+                                                                     uint32_t ngroups, uint32_t nwin, Point<C> *out) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ngroups) return;
     const uint32_t w = blockIdx.y;
@@ -78,19 +80,21 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const Point<
         q = pt_add<C>(q, running);
         running = pt_add<C>(running, base[d]);
     }
-    A[(size_t)w * ngroups + j] = running;
-    Q[(size_t)w * ngroups + j] = q;
+    out[(size_t)w * ngroups + j] = running;
+    out[(size_t)(nwin + w) * ngroups + j] = q;
 }
 
-// S[w] = SQ[w] + 2^k * S1[w]
+// Level results (one point per array, rows as above) -> S[w] = sumQ[w] + 2^k * S(A)[w],  A[w] = sumA[w]
 template <class C>
-__global__ void msm_combine_kernel(const Point<C> *SQ, const Point<C> *S1, uint32_t k, uint32_t W, Point<C> *S) {
+__global__ void msm_combine_kernel(const Point<C> *S2, const Point<C> *A2, uint32_t k, uint32_t nwin, Point<C> *S,
+                                   Point<C> *A) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
-    Point<C> x = S1[w];
+    if (w >= nwin) return;
+    Point<C> x = S2[w];
 #pragma nounroll
     for (uint32_t i = 0; i < k; i++) x = pt_dbl<C>(x);
-    S[w] = pt_add<C>(SQ[w], x);
+    S[w] = pt_add<C>(A2[nwin + w], x);
+    A[w] = A2[w];
 }
 
 // ---------------------------------------------------------------- host orchestration
@@ -120,40 +124,40 @@ struct MsmRunner {
     hipStream_t stream;
     uint32_t W;
 
-    // returns device arrays S (sum d*in[d]) and A (sum in[d]), one point per window; temporaries from `cv`
-    int reduce(const Point<C> *in, uint32_t n, Carver &cv, Point<C> **S_out, Point<C> **A_out) {
+    // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
+    int reduce(const Point<C> *in, uint32_t n, uint32_t nwin, Carver &cv, Point<C> **S_out, Point<C> **A_out) {
         const uint32_t g = 1u << MSM_G_LOG;
-        if (n <= g) {
-            Point<C> *A = (Point<C> *)cv.take(sizeof(Point<C>) * W), *Q = (Point<C> *)cv.take(sizeof(Point<C>) * W);
+        if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
+            Point<C> *out = (Point<C> *)cv.take(sizeof(Point<C>) * 2 * (size_t)nwin);
             if (cv.base) {
                 hipEvent_t pe = c.prof_begin(stream);
-                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, W), dim3(64), 0, stream, in, n, n, 1u, A, Q);
+                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, nwin), dim3(64), 0, stream, in, n, n, 1u, nwin, out);
                 c.prof_end("msm_group_sum_kernel", pe, stream);
             }
-            *S_out = Q;
-            *A_out = A;
+            *A_out = out;
+            *S_out = out ? out + nwin : nullptr;
+            if (!cv.base) *S_out = nullptr;
             return LW_OK;
         }
         const uint32_t ng = (n + g - 1) / g;
-        Point<C> *A1 = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)W * ng);
-        Point<C> *Q1 = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)W * ng);
+        Point<C> *lvl = (Point<C> *)cv.take(sizeof(Point<C>) * 2 * (size_t)nwin * ng);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((ng + MSM_THREADS - 1) / MSM_THREADS, W), dim3(MSM_THREADS), 0,
-                               stream, in, n, g, ng, A1, Q1);
+            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((ng + MSM_THREADS - 1) / MSM_THREADS, nwin), dim3(MSM_THREADS), 0,
+                               stream, in, n, g, ng, nwin, lvl);
             c.prof_end("msm_group_sum_kernel", pe, stream);
         }
-        Point<C> *S1, *Atot, *Sq_unused, *SQ;
-        int rc = reduce(A1, ng, cv, &S1, &Atot);
+        Point<C> *S2, *A2;
+        int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2);
         if (rc) return rc;
-        rc = reduce(Q1, ng, cv, &Sq_unused, &SQ);
-        if (rc) return rc;
-        Point<C> *S = (Point<C> *)cv.take(sizeof(Point<C>) * W);
+        Point<C> *S = (Point<C> *)cv.take(sizeof(Point<C>) * nwin), *A = (Point<C> *)cv.take(sizeof(Point<C>) * nwin);
         if (cv.base) {
-            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((W + 63) / 64), dim3(64), 0, stream, SQ, S1, MSM_G_LOG, W, S);
+            hipEvent_t pe = c.prof_begin(stream);
+            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, S2, A2, MSM_G_LOG, nwin, S, A);
+            c.prof_end("msm_combine_kernel", pe, stream);
         }
         *S_out = S;
-        *A_out = Atot;
+        *A_out = A;
         return LW_OK;
     }
 
@@ -222,7 +226,7 @@ struct MsmRunner {
             c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
         }
         Point<C> *A_unused;
-        return reduce(buckets, 1u << cbits, cv, S_out, &A_unused);
+        return reduce(buckets, 1u << cbits, W, cv, S_out, &A_unused);
     }
 
     int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {

@@ -78,7 +78,14 @@ struct NttPlan {
     uint32_t s0[8], r[8], logC[8];
 };
 
+static int g_ntt_cfg = 0;          // 0 = NttCfgA, 1 = NttCfgB, 2 = NttCfgC
+static uint32_t g_ntt_dbg = 0;     // diagnostics: see NttPassParams::dbg (results are wrong when set)
+void ntt_set_debug(uint32_t d) { g_ntt_dbg = d; }
+static int cfg_tile_log() { return g_ntt_cfg == 1 ? NttCfgB::TILE_LOG : NttCfgA::TILE_LOG; }
+static int cfg_kmax() { return g_ntt_cfg == 2 ? NttCfgC::KMAX : NttCfgA::KMAX; }
+
 static NttPlan plan_passes(uint32_t L, uint32_t max_r) {
+    const uint32_t NTT_TILE_LOG = (uint32_t)cfg_tile_log();
     NttPlan pl{};
     pl.npass = (int)((L + max_r - 1) / max_r);
     if (pl.npass < 1) pl.npass = 1;
@@ -97,7 +104,8 @@ static NttPlan plan_passes(uint32_t L, uint32_t max_r) {
 }
 
 static void split_steps(uint32_t r, NttPassParams &p) {
-    uint32_t nsteps = (r + 2) / 3, left = r;
+    const uint32_t NTT_KMAX = (uint32_t)cfg_kmax();
+    uint32_t nsteps = (r + NTT_KMAX - 1) / NTT_KMAX, left = r;
     p.nsteps = nsteps;
     for (uint32_t i = 0; i < nsteps; i++) {
         uint32_t k = (left + (nsteps - i) - 1) / (nsteps - i);
@@ -107,7 +115,16 @@ static void split_steps(uint32_t r, NttPassParams &p) {
 }
 
 static uint32_t g_ntt_max_r = 8;
-void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > NTT_TILE_LOG ? NTT_TILE_LOG : r); }
+void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
+void ntt_set_config(int cfg) { g_ntt_cfg = cfg < 0 || cfg > 2 ? 0 : cfg; }
+
+template <class F, class CFG>
+static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassParams &p) {
+    if (last)
+        hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG>), grid, dim3(CFG::THREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG>), grid, dim3(CFG::THREADS), 0, stream, p);
+}
 
 template <class F>
 static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bool invert, const void *d_in,
@@ -186,6 +203,7 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         const bool last = (i == pl.npass - 1);
         NttPassParams p{};
         p.tw = tw;
+        p.dbg = g_ntt_dbg;
         p.L = log2n;
         p.s0 = pl.s0[i];
         p.r = pl.r[i];
@@ -212,10 +230,9 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         const uint32_t blocks = 1u << (log2n - p.r - p.logC);
         dim3 grid(blocks, batch);
         hipEvent_t pe = c.prof_begin(stream);
-        if (last)
-            hipLaunchKernelGGL((ntt_pass_kernel<F, true>), grid, dim3(NTT_THREADS), 0, stream, p);
-        else
-            hipLaunchKernelGGL((ntt_pass_kernel<F, false>), grid, dim3(NTT_THREADS), 0, stream, p);
+        if (g_ntt_cfg == 1) launch_pass<F, NttCfgB>(last, grid, stream, p);
+        else if (g_ntt_cfg == 2) launch_pass<F, NttCfgC>(last, grid, stream, p);
+        else launch_pass<F, NttCfgA>(last, grid, stream, p);
         c.prof_end(last ? "ntt_pass_kernel<last>" : "ntt_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;

@@ -20,9 +20,22 @@
 
 namespace lw {
 
-constexpr int NTT_TILE_LOG = 11;              // 2048 elements x 32 B = 64 KiB of LDS per workgroup
-constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
-constexpr int NTT_THREADS = 256;
+// Kernel geometry: a tile of 2^TILE_LOG elements (32 B each) in LDS per workgroup, THREADS threads, and at
+// most KMAX stages per register step (2^KMAX elements per work-item).
+template <int TILE_LOG_, int THREADS_, int KMAX_>
+struct NttCfg {
+    static constexpr int TILE_LOG = TILE_LOG_;
+    static constexpr int TILE = 1 << TILE_LOG_;
+    static constexpr int THREADS = THREADS_;
+    static constexpr int KMAX = KMAX_;
+    // workgroups per CU by LDS, waves per SIMD that follow (launch bound for the register allocator)
+    static constexpr int WG_PER_CU = (160 * 1024) / (TILE * 32) > 8 ? 8 : (160 * 1024) / (TILE * 32);
+    static constexpr int WAVES_PER_SIMD = (WG_PER_CU * THREADS / 256) > 8 ? 8 : (WG_PER_CU * THREADS / 256) < 1 ? 1 : (WG_PER_CU * THREADS / 256);
+};
+using NttCfgA = NttCfg<11, 512, 2>;   // 64 KiB tile, 2 workgroups/CU, 4 waves/SIMD
+using NttCfgB = NttCfg<10, 256, 2>;   // 32 KiB tile, 5 workgroups/CU (desynchronised load/compute phases)
+using NttCfgC = NttCfg<11, 256, 3>;   // 64 KiB tile, radix-8 register steps, 2 waves/SIMD
+constexpr int NTT_MAX_TILE_LOG = 11;
 
 struct NttPassParams {
     const uint4 *in;       // element e = in[2e], in[2e+1] (reference memory layout)
@@ -35,7 +48,8 @@ struct NttPassParams {
     uint32_t r;            // stages in this pass
     uint32_t logC;         // log2 columns per tile
     uint32_t nsteps;
-    uint32_t k[4];         // stages per register step, sum = r
+    uint32_t k[8];         // stages per register step, sum = r
+    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -73,8 +87,8 @@ __device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
 }
 
 // One work-item: 2^K elements, K stages in registers.
-template <class F, int K, bool LAST>
-__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[NTT_TILE], const uint4 *gin,
+template <class F, int K, bool LAST, int TILE>
+__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
@@ -105,8 +119,13 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[NT
         uint4 q0, q1;
         if (step == 0) {
             uint64_t g = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
-            q0 = gin[2 * g];
-            q1 = gin[2 * g + 1];
+            if (p.dbg & 2) {
+                q0 = make_uint4(m, c, 1, 2);
+                q1 = make_uint4(3, 4, 5, 6);
+            } else {
+                q0 = gin[2 * g];
+                q1 = gin[2 * g + 1];
+            }
         } else {
             uint32_t idx = (m << logC) | c;
             q0 = lds[0][idx];
@@ -116,6 +135,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[NT
     }
 
     // stage u of this step == stage s0 + t0 + u of the transform
+    if (!(p.dbg & 1))
 #pragma unroll
     for (int u = 0; u < K; u++) {
         constexpr int dummy = 0; (void)dummy;
@@ -155,8 +175,11 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[NT
     }
 }
 
-template <class F, bool LAST>
-__global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) {
+template <class F, bool LAST, class CFG>
+__global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_kernel(NttPassParams p) {
+    constexpr int NTT_THREADS = CFG::THREADS;
+    constexpr int NTT_KMAX = CFG::KMAX;
+    constexpr int NTT_TILE = CFG::TILE;
     __shared__ uint4 lds[2][NTT_TILE];
     const uint32_t tid = threadIdx.x;
     const uint32_t r = p.r, logC = p.logC, L = p.L;
@@ -184,9 +207,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) 
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
-            if (k == 3) ntt_item<F, 3, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) ntt_item<F, 2, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else ntt_item<F, 1, LAST>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
         }
         t0 += k;
     }
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassParams p) 
         uint64_t g;
         if (!LAST) g = base + ((uint64_t)m << lgS) + c;
         else g = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)b << logC) + c;
-        gout[2 * g + plane] = lds[plane][e];
+        if (!(p.dbg & 4)) gout[2 * g + plane] = lds[plane][e];
     }
 }
 
