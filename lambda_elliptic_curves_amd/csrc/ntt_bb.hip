@@ -1,0 +1,317 @@
+// BabyBear (p = 2^31 - 2^27 + 1) NTT on gfx950 for the reference's three memory shapes:
+//   * U32_R32          one u32 per element, Montgomery R = 2^32  (babybear_u32.rs:6)
+//   * U64_R64          one u64 per element, Montgomery R = 2^64  (babybear.rs:19-20)
+//   * EXT4_INTERLEAVED Degree4BabyBearExtensionField values (4 x u64 per element) over a base-field domain:
+//                      F x E multiplication is four independent base products (quartic_babybear.rs:155-166), so
+//                      the transform is four interleaved base-field transforms (V = 4 components per index).
+// Same NR-DIT dataflow and pass structure as ntt_kernels.cuh (math/src/fft/cpu/fft.rs:20-55 +
+// bit_reversing.rs:2-18); registers and LDS hold u32 values in the R = 2^32 domain, the u64 shapes are
+// converted on load/store (field.cuh bb_from_r64 / bb_to_r64), which returns the same canonical residues.
+#include <vector>
+#include "context.h"
+#include "field.cuh"
+
+namespace lw {
+
+constexpr int BB_TILE_LOG = 13;            // 8192 u32 = 32 KiB of LDS
+constexpr int BB_TILE = 1 << BB_TILE_LOG;
+constexpr int BB_THREADS = 256;
+constexpr int BB_KMAX = 4;                 // radix-16 register steps
+
+struct BbPassParams {
+    const void *in;
+    void *out;
+    const uint32_t *tw;        // T[g] = w^bitrev(g), R = 2^32 domain
+    uint64_t in_batch_stride;  // in memory words
+    uint64_t out_batch_stride;
+    uint32_t L;                // log2 N (transform length)
+    uint32_t lgV;              // log2 components per index (0, or 2 for EXT4)
+    uint32_t s0, r, logC;      // logC counts columns x components
+    uint32_t nsteps;
+    uint32_t k[8];
+    uint32_t scale, sc;        // N^-1 (R = 2^32 domain) on the last pass of an inverse transform
+};
+
+__device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+template <bool W64>
+__device__ __forceinline__ uint32_t bb_load_word(const void *base, uint64_t idx) {
+    if (W64) return bb_from_r64(reinterpret_cast<const uint64_t *>(base)[idx]);
+    return reinterpret_cast<const uint32_t *>(base)[idx];
+}
+template <bool W64>
+__device__ __forceinline__ void bb_store_word(void *base, uint64_t idx, uint32_t v) {
+    if (W64) reinterpret_cast<uint64_t *>(base)[idx] = bb_to_r64(v);
+    else reinterpret_cast<uint32_t *>(base)[idx] = v;
+}
+
+template <int K, bool LAST, bool W64>
+__device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const void *gin, uint32_t w, uint32_t step,
+                                        uint32_t t0, uint64_t base, uint32_t lgS, uint32_t hi_uniform, uint32_t hi_low,
+                                        bool last_step) {
+    constexpr int E = 1 << K;
+    const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
+    const uint32_t logCh = logC - lgV;               // columns proper (distinct tiles in the last pass)
+    const uint32_t sh = r - t0 - K;
+    uint32_t c, mr;
+    if (LAST && step == 0) {   // memory order of the last pass's input is (column, row, component)
+        const uint32_t comp = w & ((1u << lgV) - 1);
+        mr = (w >> lgV) & ((1u << (r - K)) - 1);
+        c = ((w >> (lgV + r - K)) << lgV) | comp;
+    } else {
+        c = w & ((1u << logC) - 1);
+        mr = w >> logC;
+    }
+    const uint32_t m_low = mr & ((1u << sh) - 1);
+    const uint32_t m_high = mr >> sh;
+    const uint32_t mbase = (m_high << (sh + K)) | m_low;
+    uint32_t hi_c = hi_uniform;
+    if (LAST) hi_c = (bb_bitrev(c >> lgV, logCh) << (L - r - logCh)) | hi_low;
+
+    uint32_t x[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t m = mbase | ((uint32_t)j << sh);
+        if (step == 0) {
+            uint64_t g;
+            if (LAST) g = (((((uint64_t)hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
+            else g = base + ((uint64_t)m << lgS) + c;
+            x[j] = bb_load_word<W64>(gin, g);
+        } else {
+            x[j] = lds[(m << logC) | c];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+        const int half = 1 << (K - 1 - u);
+        const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
+#pragma unroll
+        for (int jt = 0; jt < (1 << u); jt++) {
+            const uint32_t tw = p.tw[gt | (uint32_t)jt];
+#pragma unroll
+            for (int jl = 0; jl < half; jl++) {
+                const int j = (jt << (K - u)) | jl;
+                const uint32_t wb = bb_mul(tw, x[j + half]);
+                const uint32_t a = x[j];
+                x[j] = bb_add(a, wb);
+                x[j + half] = bb_sub(a, wb);
+            }
+        }
+    }
+    if (last_step && p.scale) {
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = bb_mul(x[j], p.sc);
+    }
+#pragma unroll
+    for (int j = 0; j < E; j++) {
+        const uint32_t m = mbase | ((uint32_t)j << sh);
+        lds[(m << logC) | c] = x[j];
+    }
+}
+
+template <bool LAST, bool W64>
+__global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
+    __shared__ uint32_t lds[BB_TILE];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
+    const uint32_t tile_log = r + logC;
+    const uint32_t wb = W64 ? 8 : 4;
+    const char *gin = (const char *)p.in + (uint64_t)blockIdx.y * p.in_batch_stride * wb;
+    char *gout = (char *)p.out + (uint64_t)blockIdx.y * p.out_batch_stride * wb;
+    const uint32_t b = blockIdx.x;
+    const uint32_t Lw = L + lgV;      // index bits of the word array
+
+    uint64_t base = 0;
+    uint32_t lgS = 0, hi_uniform = 0, hi_low = 0;
+    if (!LAST) {
+        lgS = Lw - p.s0 - r;          // row stride in words
+        const uint32_t lo_bits = lgS - logC;
+        const uint32_t lo_blk = b & ((1u << lo_bits) - 1);
+        hi_uniform = b >> lo_bits;
+        base = ((uint64_t)hi_uniform << (Lw - p.s0)) + ((uint64_t)lo_blk << logC);
+    } else {
+        hi_low = bb_bitrev(b, L - r - (logC - lgV));
+    }
+    uint32_t t0 = 0;
+    for (uint32_t step = 0; step < p.nsteps; step++) {
+        const uint32_t k = p.k[step];
+        const uint32_t nitems = 1u << (tile_log - k);
+        const bool last_step = (step + 1 == p.nsteps);
+        if (step) __syncthreads();
+        for (uint32_t w = tid; w < nitems; w += BB_THREADS) {
+            if (k == 4) bb_item<4, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 3) bb_item<3, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) bb_item<2, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else bb_item<1, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+        }
+        t0 += k;
+    }
+    __syncthreads();
+    const uint32_t total = 1u << tile_log;
+    const uint32_t logCh = logC - lgV;
+    for (uint32_t e = tid; e < total; e += BB_THREADS) {
+        const uint32_t c = e & ((1u << logC) - 1);
+        const uint32_t m = e >> logC;
+        uint64_t g;
+        if (!LAST) g = base + ((uint64_t)m << lgS) + c;
+        else g = ((((uint64_t)bb_bitrev(m, r) << (L - r)) + ((uint64_t)b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
+        bb_store_word<W64>(gout, g, lds[e]);
+    }
+}
+
+__global__ void bb_twiddle_fill_kernel(uint32_t *tw, uint32_t root, uint32_t bits, uint64_t count) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    tw[g] = bb_pow(root, bb_bitrev((uint32_t)g, bits));
+}
+
+// x[i] *= h^i over the transform index i (all V components share the power)
+template <bool W64>
+__global__ void bb_scale_powers_kernel(const void *in, void *out, uint32_t h, uint32_t lgV, uint64_t nwords,
+                                       uint64_t in_batch_stride, uint64_t out_batch_stride) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const uint32_t wb = W64 ? 8 : 4;
+    const char *gin = (const char *)in + (uint64_t)blockIdx.y * in_batch_stride * wb;
+    char *gout = (char *)out + (uint64_t)blockIdx.y * out_batch_stride * wb;
+    uint32_t pw = bb_pow(h, i >> lgV);
+    bb_store_word<W64>(gout, i, bb_mul(bb_load_word<W64>(gin, i), pw));
+}
+
+// ---------------------------------------------------------------- host
+static uint32_t bb_host_root(uint32_t order, bool inverse) {   // traits.rs:82-94
+    if (order == 0) return BabyBear::ONE;
+    uint32_t g = bb_mul(BabyBear::ROOT, BabyBear::R2);
+    for (uint32_t i = 0; i < BabyBear::TWO_ADICITY - order; i++) g = bb_mul(g, g);
+    if (inverse) g = bb_inv(g);
+    return g;
+}
+
+static int bb_ensure_twiddles(Context &c, lw_dir_t dir, uint32_t log2n, hipStream_t stream) {
+    TwiddleTable &t = c.tw[LW_FIELD_BABYBEAR][dir];
+    if (t.valid && t.log_n >= log2n) return LW_OK;
+    if (log2n < 1) return LW_OK;
+    uint32_t L = log2n < 16 ? 16 : log2n;
+    const uint32_t bits = L - 1;
+    const uint64_t count = 1ull << bits;
+    if (t.buf.ensure(count * 4)) return LW_ERR_ALLOC;
+    const uint32_t w = bb_host_root(L, dir == LW_DIR_INVERSE);
+    hipLaunchKernelGGL(bb_twiddle_fill_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint32_t *)t.buf.p,
+                       w, bits, count);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+    t.log_n = L;
+    t.valid = true;
+    return LW_OK;
+}
+
+template <bool W64>
+static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
+                  uint64_t stride_elems, const void *coset, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    const uint64_t nwords = n << lgV;
+    const uint64_t wbytes = W64 ? 8 : 4;
+    uint64_t stride = (stride_elems ? stride_elems : n) << lgV;   // in words
+    if (log2n == 0) {
+        if (d_in != d_out)
+            LW_HIP_CHECK(hipMemcpy2DAsync(d_out, stride * wbytes, d_in, stride * wbytes, nwords * wbytes, batch,
+                                          hipMemcpyDeviceToDevice, stream), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+    int rc = bb_ensure_twiddles(c, dir, log2n, stream);
+    if (rc) return rc;
+    uint32_t h = 0;
+    if (coset) {
+        // offset is one base-field element in the layout's word type
+        h = W64 ? bb_from_r64(*(const uint64_t *)coset) : *(const uint32_t *)coset;
+        if (h == 0) { set_error("coset offset is zero"); return LW_ERR_INV_ZERO; }
+    }
+
+    // pass plan: r <= 8 stages per pass; logC columns x components fill the tile
+    const uint32_t max_r = 8;
+    int npass = (int)((log2n + max_r - 1) / max_r);
+    if (npass < 1) npass = 1;
+    const bool need_scratch = npass > 1 || d_in == d_out || (coset && dir == LW_DIR_FORWARD);
+    if (need_scratch && c.scratch.ensure((size_t)nwords * batch * wbytes)) return LW_ERR_ALLOC;
+
+    const void *src = d_in;
+    uint64_t src_stride = stride;
+    if (coset && dir == LW_DIR_FORWARD) {
+        dim3 grid((uint32_t)((nwords + 255) / 256), batch);
+        hipEvent_t pe = c.prof_begin(stream);
+        hipLaunchKernelGGL((bb_scale_powers_kernel<W64>), grid, dim3(256), 0, stream, d_in, c.scratch.p, h, lgV, nwords, stride, nwords);
+        c.prof_end("bb_scale_powers_kernel", pe, stream);
+        src = c.scratch.p;
+        src_stride = nwords;
+    }
+    if (npass == 1 && src == d_out) {
+        LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, nwords * wbytes, d_in, stride * wbytes, nwords * wbytes, batch,
+                                      hipMemcpyDeviceToDevice, stream), LW_ERR_LAUNCH);
+        src = c.scratch.p;
+        src_stride = nwords;
+    }
+    uint32_t base = log2n / npass, extra = log2n % npass, s = 0;
+    for (int i = 0; i < npass; i++) {
+        const bool last = (i == npass - 1);
+        BbPassParams p{};
+        p.tw = (const uint32_t *)c.tw[LW_FIELD_BABYBEAR][dir].buf.p;
+        p.L = log2n;
+        p.lgV = lgV;
+        p.s0 = s;
+        p.r = base + ((uint32_t)i < extra ? 1 : 0);
+        const uint32_t room = BB_TILE_LOG - p.r;
+        const uint32_t avail = last ? (log2n - p.r + lgV) : (log2n + lgV - s - p.r);
+        p.logC = room < avail ? room : avail;
+        uint32_t nsteps = (p.r + BB_KMAX - 1) / BB_KMAX, left = p.r;
+        p.nsteps = nsteps;
+        for (uint32_t q = 0; q < nsteps; q++) {
+            uint32_t k = (left + (nsteps - q) - 1) / (nsteps - q);
+            p.k[q] = k;
+            left -= k;
+        }
+        p.in = src;
+        p.in_batch_stride = src_stride;
+        if (last) {
+            if (src == d_out) { set_error("internal: last NTT pass would run in place"); return LW_ERR_BAD_ARG; }
+            p.out = d_out;
+            p.out_batch_stride = stride;
+            if (dir == LW_DIR_INVERSE) {
+                p.scale = 1;
+                p.sc = bb_inv(bb_mul((uint32_t)(n % BabyBear::P), BabyBear::R2));   // FieldElement::from(n).inv()
+            }
+        } else {
+            p.out = c.scratch.p;
+            p.out_batch_stride = nwords;
+        }
+        const uint32_t blocks = 1u << (log2n + lgV - p.r - p.logC);
+        dim3 grid(blocks, batch);
+        hipEvent_t pe = c.prof_begin(stream);
+        if (last) hipLaunchKernelGGL((bb_pass_kernel<true, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((bb_pass_kernel<false, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+        c.prof_end(last ? "bb_pass_kernel<last>" : "bb_pass_kernel", pe, stream);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        src = p.out;
+        src_stride = p.out_batch_stride;
+        s += p.r;
+    }
+    if (coset && dir == LW_DIR_INVERSE) {
+        dim3 grid((uint32_t)((nwords + 255) / 256), batch);
+        hipEvent_t pe = c.prof_begin(stream);
+        hipLaunchKernelGGL((bb_scale_powers_kernel<W64>), grid, dim3(256), 0, stream, d_out, d_out, bb_inv(h), lgV, nwords, stride, stride);
+        c.prof_end("bb_scale_powers_kernel", pe, stream);
+    }
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
+                  uint64_t stride, const void *coset_offset, hipStream_t stream) {
+    switch (layout) {
+        case LW_LAYOUT_BABYBEAR_U32_R32: return bb_run<false>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream);
+        case LW_LAYOUT_BABYBEAR_U64_R64: return bb_run<true>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream);
+        case LW_LAYOUT_EXT4_INTERLEAVED: return bb_run<true>(c, dir, 2, d_in, d_out, log2n, batch, stride, coset_offset, stream);
+        default: set_error("bad BabyBear layout %d", (int)layout); return LW_ERR_BAD_ARG;
+    }
+}
+
+}  // namespace lw
