@@ -4,9 +4,11 @@
 A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
   * NTT leg (the `value`): one forward Stark252 NTT of 2^log2n elements (Polynomial::evaluate_fft backend arm),
   * MSM leg (reported under "msm"): one BLS12-381 G1 Pippenger MSM of 2^msm_log2n points.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the units are independent transforms / point
-sets, one per rank (STARK columns / SRS shards) — weak scaling, no data-path collective
-for the NTT leg; the MSM leg combines the per-rank partial sums with one all_gather of a single point.
+N > 1 (launched by torch.distributed.run, one rank per GPU), weak scaling — per-GPU work is fixed:
+  * NTT leg: ONE transform of N_gpus * 2^log2n elements block-distributed over the ranks (four-step over RCCL
+    all-to-all, lambda_elliptic_curves_amd/distributed.py); --dist-mode independent instead gives every rank its
+    own 2^log2n transform (STARK columns, no collective);
+  * MSM leg: every rank holds 2^msm_log2n (scalar, point) pairs; partial sums are combined with one all_gather.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,6 +42,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=24, help="NTT size (Stark252)")
     ap.add_argument("--msm-log2n", type=int, default=20, help="MSM size (BLS12-381 G1)")
     ap.add_argument("--workload", choices=["ntt", "msm", "all"], default="all")
+    ap.add_argument("--dist-mode", choices=["sharded", "independent"], default="sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-log2n", type=int, default=24, help="CPU baseline sample size")
     args = ap.parse_args()
@@ -92,13 +95,38 @@ def main():
         t_in = torch.from_numpy(host.view(np.int64)).cuda()
         t_out = torch.empty_like(t_in)
         del host
-        for _ in range(args.warmup):
+        dist_mode = "single" if world == 1 else args.dist_mode
+        comm = None
+        if dist_mode == "sharded":
+            from lambda_elliptic_curves_amd import distributed as D
+            comm = D.TorchDistComm()
+            t_in = t_in.view(n, 4)
+
+        def step():
+            if dist_mode == "sharded":
+                return D.ntt_sharded(fld, t_in, L + (world.bit_length() - 1), comm)
             fft.ntt_device(fld, t_in, t_out, L)
+            return t_out
+
+        try:
+            for _ in range(args.warmup):
+                step()
+        except Exception as e:   # keep the run measurable if the collective path is unavailable on this node
+            if dist_mode != "sharded":
+                raise
+            dist_mode = "independent (sharded failed: %s)" % str(e)[:120]
+            t_in = t_in.view(-1)
+            t_in = t_in.view(n, 4)
+            for _ in range(args.warmup):
+                fft.ntt_device(fld, t_in, t_out, L)
         barrier()
         _lib.profile_begin()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            fft.ntt_device(fld, t_in, t_out, L)
+            if dist_mode == "sharded":
+                step()
+            else:
+                fft.ntt_device(fld, t_in, t_out, L)
         barrier()
         dt = time.perf_counter() - t0
         prof = _lib.profile_end()
@@ -108,7 +136,7 @@ def main():
         # dominant kernel = the LDS-tiled NTT pass (all passes of one transform are launches of it)
         launches = sum(v[0] for k, v in prof.items() if k.startswith("ntt_pass_kernel"))
         total_ms = sum(v[1] for k, v in prof.items() if k.startswith("ntt_pass_kernel"))
-        passes = launches // max(args.steps, 1)
+        passes = max(launches // max(args.steps, 1), 1)
         avg_launch_ms = total_ms / max(launches, 1)
         alg_bytes_per_launch = 2.0 * n * 32 / max(passes, 1)     # 2*N*B per transform, spread over its passes
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
@@ -128,8 +156,10 @@ def main():
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (256-bit Montgomery, 32-bit limbs)", "data": "synthetic",
-            "config": {"workload": "Stark252 NTT 2^%d forward, 1 transform per GPU, inputs resident in HBM" % L,
-                       "field": "Stark252", "log2n": L, "passes": passes, "parallelism": "independent transforms per rank"},
+            "config": {"workload": ("Stark252 NTT 2^%d forward, inputs resident in HBM" % L) if world == 1 else
+                                   ("Stark252 NTT, 2^%d elements per GPU x %d GPUs, %s" % (L, world, dist_mode)),
+                       "field": "Stark252", "log2n": L, "log2n_total": L + (world.bit_length() - 1 if dist_mode == "sharded" else 0),
+                       "passes": passes, "parallelism": dist_mode},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ntt_pass_kernel", "avg_launch_ms": avg_launch_ms, "launches": launches,

@@ -36,18 +36,21 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
     t_sc = torch.from_numpy(scalars.view(np.int64)).cuda()
     steps = max(1, min(args.steps, 5))
     warm = max(1, min(args.warmup, 2))
+    from lambda_elliptic_curves_amd import distributed as D
+    comm = D.TorchDistComm() if world > 1 else None
+
+    def step():
+        if world > 1:   # per-rank Pippenger + all_gather of the partial sums + final adds
+            return D.msm_sharded(crv, t_sc, t_pts, n, comm)
+        return msm.msm_device(crv, t_sc, t_pts, n)
+
     for _ in range(warm):
-        out = msm.msm_device(crv, t_sc, t_pts, n)
+        out = step()
     barrier()
     _lib.profile_begin()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = msm.msm_device(crv, t_sc, t_pts, n)
-        if world > 1:
-            # combine the per-rank partial sums: all_gather of one projective point, then local adds
-            t = torch.from_numpy(out.view(np.int64)).cuda()
-            gathered = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(gathered, t)
+        out = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()

@@ -122,6 +122,17 @@ int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const 
                       uint32_t log2n, uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null,
                       void *hip_stream);
 
+/* Cross-shard step of the multi-GPU NTT (no reference counterpart: the reference has no multi-device path).
+ * A 2^log2n_total vector is block-distributed over G = 2^log2_shards GPUs (M = N/G elements each).  After the
+ * first all-to-all this rank holds x[j1][j2] for j1 = 0..G-1 and its slice j2 in [j2_begin, j2_begin+slice_len),
+ * chunk j1 starting chunk_stride_elems*j1 elements into d_in.  Writes, with the same chunking over k1,
+ *     y[k1][j2] = w_N^(j2*k1) * sum_j1 w_G^(j1*k1) * x[j1][j2]        (inverse: inverse roots, times G^-1).
+ * The second all-to-all then gives rank k1 the row y[k1][0..M), whose local M-point NTT (lw_hip_ntt_device) is
+ * X[k1 + G*k2].  See lambda_elliptic_curves_amd/distributed.py for the full exchange schedule. */
+int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                            uint32_t log2n_total, uint32_t log2_shards, uint64_t j2_begin, uint64_t slice_len,
+                            uint64_t chunk_stride_elems, uint32_t batch, uint64_t batch_stride_elems, void *hip_stream);
+
 /* ---- Polynomial FFT API (host buffers, reference semantics) ----
  * evaluate: len = max(coeff_len, domain_size).next_power_of_two() * blowup_factor where coeff_len is
  * taken after stripping trailing zero coefficients (Polynomial::new); writes *out_len elements.  Call with

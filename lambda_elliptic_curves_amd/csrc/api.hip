@@ -116,6 +116,9 @@ int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in
                   uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream);
+int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                     uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
+                     uint32_t batch, uint64_t batch_stride, hipStream_t stream);
 
 static uint32_t two_adicity(lw_field_t f) {
     switch (f) {
@@ -202,7 +205,7 @@ void lw_hip_shutdown(void) {
         }
     c.scratch.release();
     c.small.release();
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         c.coset[i].lo.release();
         c.coset[i].hi.release();
         c.coset[i].valid = false;
@@ -299,6 +302,23 @@ int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const 
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.ntt_calls++;
     return rc;
+}
+
+int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                            uint32_t log2n_total, uint32_t log2_shards, uint64_t j2_begin, uint64_t slice_len,
+                            uint64_t chunk_stride_elems, uint32_t batch, uint64_t batch_stride_elems, void *hip_stream) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (log2n_total > 63) { set_error("order %u > 63", log2n_total); return LW_ERR_ORDER_TOO_LARGE; }
+    if (log2n_total > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n_total); return LW_ERR_ROOT_OF_UNITY; }
+    if (!d_in || !d_out || d_in == d_out) { set_error("cross step needs distinct non-null buffers"); return LW_ERR_BAD_ARG; }
+    if (batch == 0 || slice_len == 0) return LW_OK;
+    return ntt_cross_device(c, field, layout, dir, d_in, d_out, log2n_total, log2_shards, j2_begin, slice_len, chunk_stride_elems,
+                            batch, batch_stride_elems, (hipStream_t)hip_stream);
 }
 
 int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t log2n, uint32_t batch,

@@ -40,6 +40,7 @@ struct TwiddleTable {
 struct CosetCache {
     DeviceBuf lo, hi;
     uint32_t hbits = 0;
+    uint32_t hi_bits = 0;
     uint32_t words[8] = {0};
     int field = -1;
     bool inverse = false;
@@ -65,7 +66,7 @@ struct Context {
     TwiddleTable tw[3][2];   // [field][dir]
     DeviceBuf scratch;
     DeviceBuf small;         // staging for small power tables
-    CosetCache coset[2];
+    CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     lw_timings_t timings = {};

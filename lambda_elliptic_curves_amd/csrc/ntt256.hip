@@ -126,13 +126,12 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
         hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG>), grid, dim3(CFG::THREADS), 0, stream, p);
 }
 
+// cached two-level power tables of `base` (optionally inverted): base^e = lo[e & mask] * hi[e >> hbits]
 template <class F>
-static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bool invert, const void *d_in,
-                           void *d_out, uint32_t log2n, uint32_t batch, uint64_t in_stride, uint64_t out_stride,
-                           hipStream_t stream) {
-    CosetCache &cc = c.coset[invert ? 1 : 0];
-    const uint32_t hbits = (log2n + 1) / 2;
-    bool hit = cc.valid && cc.field == field && cc.hbits == hbits && cc.inverse == invert;
+static int power_tables(Context &c, int field, int slot, const uint32_t *base_words, bool invert, uint32_t hbits,
+                        uint32_t hi_bits, hipStream_t stream, const uint4 **lo, const uint4 **hi) {
+    CosetCache &cc = c.coset[slot];
+    bool hit = cc.valid && cc.field == field && cc.hbits == hbits && cc.hi_bits == hi_bits && cc.inverse == invert;
     for (int i = 0; i < 8 && hit; i++) hit = cc.words[i] == base_words[i];
     if (!hit) {
         Fe<F> b;
@@ -143,20 +142,34 @@ static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bo
         }
         if (invert) b = fe_inv<F>(b);
         LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);   // previous users of the cached tables
-        int rc = upload_power_tables<F>(b, hbits, 1ull << (log2n - hbits), cc.lo, cc.hi);
+        int rc = upload_power_tables<F>(b, hbits, 1ull << hi_bits, cc.lo, cc.hi);
         if (rc) return rc;
         cc.valid = true;
         cc.field = field;
         cc.hbits = hbits;
+        cc.hi_bits = hi_bits;
         cc.inverse = invert;
         for (int i = 0; i < 8; i++) cc.words[i] = base_words[i];
     }
+    *lo = (const uint4 *)cc.lo.p;
+    *hi = (const uint4 *)cc.hi.p;
+    return LW_OK;
+}
+
+template <class F>
+static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bool invert, const void *d_in,
+                           void *d_out, uint32_t log2n, uint32_t batch, uint64_t in_stride, uint64_t out_stride,
+                           hipStream_t stream) {
+    const uint32_t hbits = (log2n + 1) / 2;
+    const uint4 *lo, *hi;
+    int rc = power_tables<F>(c, field, invert ? 1 : 0, base_words, invert, hbits, log2n - hbits, stream, &lo, &hi);
+    if (rc) return rc;
     const uint64_t n = 1ull << log2n;
     const uint32_t threads = 256;
     dim3 grid((uint32_t)((n + threads - 1) / threads), batch);
     hipEvent_t pe = c.prof_begin(stream);
-    hipLaunchKernelGGL((scale_powers_kernel<F>), grid, dim3(threads), 0, stream, (const uint4 *)d_in, (uint4 *)d_out,
-                       (const uint4 *)cc.lo.p, (const uint4 *)cc.hi.p, hbits, n, in_stride, out_stride);
+    hipLaunchKernelGGL((scale_powers_kernel<F>), grid, dim3(threads), 0, stream, (const uint4 *)d_in, (uint4 *)d_out, lo, hi,
+                       hbits, n, in_stride, out_stride);
     c.prof_end("scale_powers_kernel", pe, stream);
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     return LW_OK;
@@ -244,6 +257,38 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         if (rc) return rc;
     }
     return LW_OK;
+}
+
+// ---- helpers for the multi-GPU cross step (ntt_cross.hip)
+int ntt256_power_tables(Context &c, int field, int slot, const uint32_t *base_words, bool invert, uint32_t hbits,
+                        uint32_t hi_bits, hipStream_t stream, const uint4 **lo, const uint4 **hi) {
+    if (field == LW_FIELD_STARK252) return power_tables<Stark252>(c, field, slot, base_words, invert, hbits, hi_bits, stream, lo, hi);
+    return power_tables<Fr381>(c, field, slot, base_words, invert, hbits, hi_bits, stream, lo, hi);
+}
+int ntt256_root_words(int field, uint32_t order, bool inverse, uint32_t *words) {
+    if (field == LW_FIELD_STARK252) {
+        Fe<Stark252> w = host_root_of_unity<Stark252>(order, inverse);
+        for (int i = 0; i < 8; i++) words[i] = w.v[i];
+    } else {
+        Fe<Fr381> w = host_root_of_unity<Fr381>(order, inverse);
+        for (int i = 0; i < 8; i++) words[i] = w.v[i];
+    }
+    return LW_OK;
+}
+int ntt256_inv_u64_words(int field, uint64_t v, uint32_t *words) {
+    if (field == LW_FIELD_STARK252) {
+        Fe<Stark252> w = fe_inv<Stark252>(fe_from_u64<Stark252>(v));
+        for (int i = 0; i < 8; i++) words[i] = w.v[i];
+    } else {
+        Fe<Fr381> w = fe_inv<Fr381>(fe_from_u64<Fr381>(v));
+        for (int i = 0; i < 8; i++) words[i] = w.v[i];
+    }
+    return LW_OK;
+}
+const uint4 *ntt256_twiddle_table(Context &c, int field, lw_dir_t dir, uint32_t log2n, hipStream_t stream, int *rc) {
+    *rc = field == LW_FIELD_STARK252 ? ensure_twiddles<Stark252>(c, field, dir, log2n, stream)
+                                     : ensure_twiddles<Fr381>(c, field, dir, log2n, stream);
+    return (const uint4 *)c.tw[field][dir].buf.p;
 }
 
 int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,

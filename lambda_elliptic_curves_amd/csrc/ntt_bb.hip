@@ -304,6 +304,12 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
     return LW_OK;
 }
 
+const uint32_t *ntt_bb_twiddle_table(Context &c, lw_dir_t dir, uint32_t log2n, hipStream_t stream, int *rc) {
+    *rc = bb_ensure_twiddles(c, dir, log2n, stream);
+    return (const uint32_t *)c.tw[LW_FIELD_BABYBEAR][dir].buf.p;
+}
+uint32_t ntt_bb_root(uint32_t order, bool inverse) { return bb_host_root(order, inverse); }
+
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
                   uint64_t stride, const void *coset_offset, hipStream_t stream) {
     switch (layout) {

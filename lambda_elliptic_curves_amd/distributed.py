@@ -1,0 +1,171 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no multi-device code at all; these entry points produce the same results as the
+single-device API on the concatenated input.
+
+* ntt_sharded   one large transform block-distributed over G = 2/4/8 ranks (Bailey four-step with N1 = G):
+                all-to-all -> cross-shard step (lw_hip_ntt_cross_device) -> all-to-all -> local M-point NTT
+                (lw_hip_ntt_device) [-> all-to-all + local interleave for natural block order].
+                xGMI is a full mesh, so every all-to-all keeps all 7 links busy; payload per rank and exchange
+                is (G-1)/G of the local shard.
+* msm_sharded   points (and scalars) are sharded; each rank runs the full Pippenger on its shard, the G partial
+                sums are all-gathered (one point each) and added.  RCCL has no user-defined reduction, so the
+                "bucket all-reduce" of the north star is an all-gather + local group adds of tiny payloads.
+* batches with batch >= G need no collective: give each rank whole columns (fft.ntt_device per rank).
+
+`comm` abstracts the process group so the same SPMD code runs under torch.distributed (NCCL = RCCL on ROCm,
+or gloo on CPU for tests) and under an in-process simulator of G virtual ranks (tests on a single GPU).
+`backend` abstracts the local compute; the default is the HIP library (there is no CPU fallback).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .errors import check
+
+
+# ---------------------------------------------------------------- communicators
+class TorchDistComm:
+    """torch.distributed process group (backend 'nccl' is RCCL on ROCm; 'gloo' for CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def all_to_all(self, send):
+        """send: tensor [G, ...] — chunk h goes to rank h; returns [G, ...] with chunk j from rank j."""
+        import torch
+        send = send.contiguous()
+        recv = torch.empty_like(send)
+        self.dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def all_gather(self, t):
+        import torch
+        out = [torch.empty_like(t) for _ in range(self.size)]
+        self.dist.all_gather(out, t.contiguous(), group=self.group)
+        return out
+
+
+class SimComm:
+    """G virtual ranks inside one process (one Python thread each) — for exercising the SPMD schedule on one GPU."""
+
+    class _Shared:
+        def __init__(self, size):
+            import threading
+            self.size = size
+            self.barrier = threading.Barrier(size)
+            self.slots = [None] * size
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.size = shared, rank, shared.size
+
+    @classmethod
+    def make(cls, size):
+        sh = cls._Shared(size)
+        return [cls(sh, r) for r in range(size)]
+
+    def _exchange(self, payload):
+        sh = self.shared
+        sh.slots[self.rank] = payload
+        sh.barrier.wait()
+        got = list(sh.slots)
+        sh.barrier.wait()
+        return got
+
+    def all_to_all(self, send):
+        import torch
+        everyone = self._exchange(send.contiguous())
+        return torch.stack([everyone[j][self.rank] for j in range(self.size)])
+
+    def all_gather(self, t):
+        return [x.clone() for x in self._exchange(t.contiguous())]
+
+
+# ---------------------------------------------------------------- local compute
+class HipBackend:
+    """Local steps on the GPU through the C ABI (device-resident torch tensors, torch's current stream)."""
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def cross(self, field, t_in, log2n_total, log2g, j2_begin, slice_len, inverse):
+        import torch
+        t_out = torch.empty_like(t_in)
+        check(L.lib().lw_hip_ntt_cross_device(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD,
+                                              C.c_void_p(t_in.data_ptr()), C.c_void_p(t_out.data_ptr()), log2n_total, log2g,
+                                              j2_begin, slice_len, slice_len, 1, 0, self._stream()))
+        return t_out
+
+    def local_ntt(self, field, t_in, log2m, inverse):
+        import torch
+        from . import fft
+        t_out = torch.empty_like(t_in)
+        fft.ntt_device(field, t_in, t_out, log2m, inverse=inverse)
+        return t_out
+
+    def local_msm(self, curve, t_scalars, t_points, n):
+        from . import msm
+        return msm.msm_device(curve, t_scalars, t_points, n)
+
+    def sum_points(self, curve, pts):
+        """Sum of a handful of projective points = MSM with unit scalars (runs on the same HIP path)."""
+        from . import msm
+        ones = np.zeros((len(pts), 4), np.uint64)
+        ones[:, 3] = 1
+        return msm.msm(curve, ones, np.stack(pts))
+
+
+def _log2(n):
+    if n <= 0 or n & (n - 1):
+        raise ValueError(f"{n} is not a power of two")
+    return n.bit_length() - 1
+
+
+# ---------------------------------------------------------------- sharded NTT
+def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, natural_output=True):
+    """x_local: this rank's contiguous block of the natural-order vector, tensor [M, words] (M = N / G).
+    Returns this rank's block of the natural-order result (natural_output=True), or the cyclic shard
+    X[rank + G*k2] (one exchange fewer; convenient when a bit-reverse + commit follows)."""
+    backend = backend or HipBackend()
+    G, g = comm.size, comm.rank
+    if G == 1:
+        return backend.local_ntt(field, x_local, log2n_total, inverse)
+    lg = _log2(G)
+    if lg > 3:
+        raise ValueError("ntt_sharded supports 2, 4 or 8 ranks")
+    M = x_local.shape[0]
+    if (M << lg) != (1 << log2n_total) or M % G:
+        raise ValueError(f"local shard of {M} elements does not match 2^{log2n_total} over {G} ranks")
+    sl = M // G
+    tail = tuple(x_local.shape[1:])
+    # 1. all-to-all: slice h of j2 goes to rank h  ->  [G (j1), sl, ...]
+    recv = comm.all_to_all(x_local.reshape((G, sl) + tail))
+    # 2. cross-shard step on this rank's j2 slice
+    y = backend.cross(field, recv.reshape((G * sl,) + tail), log2n_total, lg, g * sl, sl, inverse)
+    # 3. all-to-all: row k1 goes to rank k1  ->  Y[g][all j2]
+    row = comm.all_to_all(y.reshape((G, sl) + tail)).reshape((M,) + tail)
+    # 4. local M-point transform: z[k2] = X[g + G*k2]
+    z = backend.local_ntt(field, row, log2n_total - lg, inverse)
+    if not natural_output:
+        return z
+    # 5. all-to-all + local interleave: natural index g*M + (k1 + G*k2')
+    recv3 = comm.all_to_all(z.reshape((G, sl) + tail))          # [k1, k2', ...]
+    return recv3.transpose(0, 1).contiguous().reshape((M,) + tail)
+
+
+# ---------------------------------------------------------------- sharded MSM
+def msm_sharded(curve, t_scalars, t_points, n_local, comm, backend=None):
+    """Every rank holds n_local (scalar, point) pairs; returns sum over all ranks' pairs on every rank."""
+    import torch
+    backend = backend or HipBackend()
+    part = backend.local_msm(curve, t_scalars, t_points, n_local)          # numpy projective point
+    if comm.size == 1:
+        return part
+    t = torch.from_numpy(np.ascontiguousarray(part).view(np.int64)).to(t_scalars.device)
+    parts = [p.cpu().numpy().view(np.uint64) for p in comm.all_gather(t)]
+    return backend.sum_points(curve, parts)
