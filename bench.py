@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=24, help="NTT size (Stark252)")
-    ap.add_argument("--msm-log2n", type=int, default=20, help="MSM size (BLS12-381 G1)")
+    ap.add_argument("--msm-log2n", type=int, default=24, help="MSM size (BLS12-381 G1)")
     ap.add_argument("--workload", choices=["ntt", "msm", "all"], default="all")
     ap.add_argument("--dist-mode", choices=["sharded", "independent"], default="sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")

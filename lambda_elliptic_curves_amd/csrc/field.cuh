@@ -25,6 +25,8 @@ namespace lw {
 // p(i), one(i), r2(i): 32-bit limb i (LS first) of the modulus, R mod p, R^2 mod p.  INV = -p^-1 mod 2^32.
 struct Stark252 {   // math/src/field/fields/fft_friendly/stark_252_prime_field.rs:13-24
     static constexpr int N = 8;
+    // p < 2^252: 2^256 / p ~ 32, so NTT butterflies can carry values in [0, 24p) between reductions
+    static constexpr bool LAZY = true;
     static constexpr uint32_t INV = 0xffffffffu;
     static constexpr uint32_t TWO_ADICITY = 192;
     LW_HD static constexpr uint32_t p(int i) {
@@ -47,6 +49,7 @@ struct Stark252 {   // math/src/field/fields/fft_friendly/stark_252_prime_field.
 };
 struct Fr381 {      // math/src/elliptic_curve/short_weierstrass/curves/bls12_381/default_types.rs:15-30
     static constexpr int N = 8;
+    static constexpr bool LAZY = false;   // 255-bit modulus: no headroom above 2p
     static constexpr uint32_t INV = 0xffffffffu;
     static constexpr uint32_t TWO_ADICITY = 32;
     LW_HD static constexpr uint32_t p(int i) {
@@ -278,6 +281,25 @@ __device__ __forceinline__ void mac96_x4(uint64_t &lo, uint32_t &hi, uint32_t a0
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
         : "vcc");
 }
+// Column start: acc(96) = init(64) + a0*b0 [+ ...].  The first MAC takes the previous column's carry as its
+// addend and the first add-with-carry materialises the top word (0 + 0 + carry), so a column change costs one
+// register copy instead of three.
+#define LW_MAC_FIRST(A, B, INIT) "v_mad_u64_u32 %0, vcc, " A ", " B ", " INIT "\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc\n\t"
+__device__ __forceinline__ void mac96_first_x1(uint64_t &lo, uint32_t &hi, uint64_t init, uint32_t a0, uint32_t b0) {
+    asm(LW_MAC_FIRST("%3", "%4", "%2") : "=v"(lo), "=v"(hi) : "v"(init), "v"(a0), "v"(b0) : "vcc");
+}
+__device__ __forceinline__ void mac96_first_x2(uint64_t &lo, uint32_t &hi, uint64_t init, uint32_t a0, uint32_t b0, uint32_t a1,
+                                               uint32_t b1) {
+    asm(LW_MAC_FIRST("%3", "%4", "%2") LW_MAC_V("%5", "%6")
+        : "=&v"(lo), "=&v"(hi) : "v"(init), "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+}
+__device__ __forceinline__ void mac96_first_x4(uint64_t &lo, uint32_t &hi, uint64_t init, uint32_t a0, uint32_t b0, uint32_t a1,
+                                               uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3) {
+    asm(LW_MAC_FIRST("%3", "%4", "%2") LW_MAC_V("%5", "%6") LW_MAC_V("%7", "%8") LW_MAC_V("%9", "%10")
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(init), "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3)
+        : "vcc");
+}
 // acc(96) += m * C for a compile-time constant C
 template <uint32_t C>
 __device__ __forceinline__ void mac96_c1(uint64_t &lo, uint32_t &hi, uint32_t m0) {
@@ -328,34 +350,49 @@ __device__ __forceinline__ void col_mp(uint64_t &lo, uint32_t &hi, const uint32_
         col_mp<F, K, I + 1, IEND>(lo, hi, m);
     }
 }
-template <class F, int K>
-__device__ __forceinline__ void fips_col(uint64_t &lo, uint32_t &hi, const Fe<F> &a, const Fe<F> &b, uint32_t (&m)[F::N],
-                                         uint32_t (&t)[F::N]) {
-    constexpr int N = F::N;
-    if constexpr (K < N) {
-        col_ab<F, K, 0, K + 1>(lo, hi, a, b);
-        col_mp<F, K, 0, K>(lo, hi, m);
-        uint32_t mk;
-        if constexpr (F::INV == 0xffffffffu) mk = 0u - (uint32_t)lo;
-        else mk = (uint32_t)lo * F::INV;
-        m[K] = mk;
-        mac96_c1<F::p(0)>(lo, hi, mk);
+// column K, first chunk: acc = init + a[I]*b[K-I] + ...; returns via lo/hi, continues with col_ab
+template <class F, int K, int I, int IEND>
+__device__ __forceinline__ void col_ab_first(uint64_t &lo, uint32_t &hi, uint64_t init, const Fe<F> &a, const Fe<F> &b) {
+    if constexpr (I + 4 <= IEND) {
+        mac96_first_x4(lo, hi, init, a.v[I], b.v[K - I], a.v[I + 1], b.v[K - I - 1], a.v[I + 2], b.v[K - I - 2], a.v[I + 3], b.v[K - I - 3]);
+        col_ab<F, K, I + 4, IEND>(lo, hi, a, b);
+    } else if constexpr (I + 2 <= IEND) {
+        mac96_first_x2(lo, hi, init, a.v[I], b.v[K - I], a.v[I + 1], b.v[K - I - 1]);
+        col_ab<F, K, I + 2, IEND>(lo, hi, a, b);
     } else {
-        col_ab<F, K, K - N + 1, N>(lo, hi, a, b);
-        col_mp<F, K, K - N + 1, N>(lo, hi, m);
-        t[K - N] = (uint32_t)lo;
+        static_assert(I + 1 <= IEND, "column without products");
+        mac96_first_x1(lo, hi, init, a.v[I], b.v[K - I]);
     }
-    lo = (lo >> 32) | ((uint64_t)hi << 32);
-    hi = 0;
-    if constexpr (K + 1 < 2 * N) fips_col<F, K + 1>(lo, hi, a, b, m, t);
+}
+template <class F, int K>
+__device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe<F> &b, uint32_t (&m)[F::N], uint32_t (&t)[F::N]) {
+    constexpr int N = F::N;
+    if constexpr (K == 2 * N - 1) {
+        t[N - 1] = (uint32_t)init;   // no products left: the last carry is the top limb
+    } else {
+        uint64_t lo;
+        uint32_t hi;
+        if constexpr (K < N) {
+            col_ab_first<F, K, 0, K + 1>(lo, hi, init, a, b);
+            col_mp<F, K, 0, K>(lo, hi, m);
+            uint32_t mk;
+            if constexpr (F::INV == 0xffffffffu) mk = 0u - (uint32_t)lo;
+            else mk = (uint32_t)lo * F::INV;
+            m[K] = mk;
+            mac96_c1<F::p(0)>(lo, hi, mk);
+        } else {
+            col_ab_first<F, K, K - N + 1, N>(lo, hi, init, a, b);
+            col_mp<F, K, K - N + 1, N>(lo, hi, m);
+            t[K - N] = (uint32_t)lo;
+        }
+        fips_col<F, K + 1>((lo >> 32) | ((uint64_t)hi << 32), a, b, m, t);
+    }
 }
 template <class F>
 __device__ __forceinline__ Fe<F> fe_mul_gfx9(const Fe<F> &a, const Fe<F> &b) {
     constexpr int N = F::N;
     uint32_t m[N], t[N];
-    uint64_t lo = 0;
-    uint32_t hi = 0;
-    fips_col<F, 0>(lo, hi, a, b, m, t);
+    fips_col<F, 0>(0ull, a, b, m, t);
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
@@ -374,6 +411,110 @@ LW_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
 
 template <class F>
 LW_HD Fe<F> fe_sqr(const Fe<F> &a) { return fe_mul<F>(a, a); }
+
+// ---- lazy-reduction helpers (fields with F::LAZY; used by the NTT butterflies only) ----
+// limb i of K*p for K a power of two
+template <class F, int LOGK>
+LW_HD constexpr uint32_t kp_limb(int i) {
+    if (LOGK == 0) return F::p(i);
+    return (F::p(i) << LOGK) | (i > 0 ? (F::p(i - 1) >> (32 - LOGK)) : 0u);
+}
+// a - K*p if a >= K*p else a
+template <class F, int LOGK>
+LW_HD Fe<F> fe_cond_sub_kp(const Fe<F> &a) {
+    constexpr int N = F::N;
+    Fe<F> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)a.v[i] - kp_limb<F, LOGK>(i) - borrow;
+        d.v[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+// Full reduction of any 256-bit value for p = 2^251 + 17*2^192 + 1 (Stark252): q = x >> 251 is floor(x/p) or one
+// more (x*(p - 2^251)/(p*2^251) < 2^-48), and q*p = q + 17q*2^192 + q*2^251 needs no multiplication chain:
+// one 8-limb subtraction plus a conditional add of p.
+LW_HD Fe<Stark252> fe_reduce_full(const Fe<Stark252> &x) {
+    const uint32_t q = x.v[7] >> 27;
+    const uint32_t sub[8] = {q, 0, 0, 0, 0, 0, 17u * q, q << 27};
+    Fe<Stark252> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)x.v[i] - sub[i] - borrow;
+        d.v[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    const uint32_t mask = borrow ? 0xffffffffu : 0u;
+    Fe<Stark252> r;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)d.v[i] + (Stark252::p(i) & mask);
+        r.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return r;
+}
+template <class F>
+LW_HD Fe<F> fe_reduce_full(const Fe<F> &x) { return reduce_once<F>(x); }   // non-lazy fields never leave [0, 2p)
+
+// plain N-limb add / (a + 2p - b); the caller guarantees the range fits N limbs
+template <class F>
+LW_HD Fe<F> fe_add_raw(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N;
+    Fe<F> s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a.v[i] + b.v[i];
+        s.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return s;
+}
+template <class F>
+LW_HD Fe<F> fe_add2p_sub_raw(const Fe<F> &a, const Fe<F> &b) {   // a + 2p - b, b <= a + 2p
+    constexpr int N = F::N;
+    Fe<F> s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a.v[i] + kp_limb<F, 1>(i);
+        s.v[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    Fe<F> d;
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t t = (uint64_t)s.v[i] - b.v[i] - borrow;
+        d.v[i] = (uint32_t)t;
+        borrow = (t >> 32) & 1;
+    }
+    return d;
+}
+// Montgomery product without the final conditional subtraction: result in [0, 2p) whenever a < p
+// (b may be any N-limb value): (a*b + m*p) / R < a*b/R + p < 2p.
+template <class F>
+LW_HD Fe<F> fe_mul_lazy(const Fe<F> &a, const Fe<F> &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int N = F::N;
+    uint32_t m[N], t[N];
+    fips_col<F, 0>(0ull, a, b, m, t);
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return r;
+#else
+    return fe_mul_portable<F>(a, b);
+#endif
+}
 
 // x^e for a small exponent, Montgomery domain
 template <class F>

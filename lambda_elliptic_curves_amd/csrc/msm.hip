@@ -16,6 +16,7 @@
 //                  the second term being the same problem on n/g points.
 //   5. combine     the <= 64 window sums are folded most-significant first, acc <- 2^c * acc + S_w
 //                  (pippenger.rs:101), on the host with the same limb code, and normalised to (x/z : y/z : 1).
+#include <stdlib.h>
 #include "msm_core.cuh"
 
 namespace lw {
@@ -62,26 +63,60 @@ __global__ void msm_scatter_kernel(const uint32_t *scalars, uint64_t n, uint32_t
     }
 }
 
-// Single-workgroup scan.  mode 0: in = counts[K]            -> out[K+1] = exclusive scan(counts)
-//                         mode 1: in = segment offsets[K+1] -> out[K+1] = exclusive scan(ceil(len/CH))
+// Exclusive scan over K keys in three launches (block partials -> top scan -> final).
+//   mode 0: in = counts[K]            -> out[K+1] = exclusive scan(counts)
+//   mode 1: in = segment offsets[K+1] -> out[K+1] = exclusive scan(ceil(len/CH))
 // *maxlen receives the largest count / segment length seen.
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *in, uint32_t *out, uint32_t K, int mode,
-                                                        uint32_t *maxlen) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t pmax[1024];
+constexpr uint32_t SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ uint32_t scan_len(const uint32_t *in, uint32_t k, int mode) { return mode ? (in[k + 1] - in[k]) : in[k]; }
+__device__ __forceinline__ uint32_t scan_val(uint32_t len, int mode) { return mode ? (len + MSM_CH - 1) / MSM_CH : len; }
+
+__global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_partial_kernel(const uint32_t *in, uint32_t K, int mode, uint32_t *bsum,
+                                                                      uint32_t *bmax) {
+    __shared__ uint32_t ssum[SCAN_BLOCK], smax[SCAN_BLOCK];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_TILE + tid * SCAN_ITEMS;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t k = base + i;
+        if (k < K) {
+            uint32_t len = scan_len(in, k, mode);
+            mx = max(mx, len);
+            sum += scan_val(len, mode);
+        }
+    }
+    ssum[tid] = sum;
+    smax[tid] = mx;
+    __syncthreads();
+    for (uint32_t d = SCAN_BLOCK / 2; d > 0; d >>= 1) {
+        if (tid < d) {
+            ssum[tid] += ssum[tid + d];
+            smax[tid] = max(smax[tid], smax[tid + d]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        bsum[blockIdx.x] = ssum[0];
+        bmax[blockIdx.x] = smax[0];
+    }
+}
+
+// one workgroup: exclusive scan of the block sums in place, total -> out[K], max -> *maxlen
+__global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t *bsum, const uint32_t *bmax, uint32_t nblocks, uint32_t *out,
+                                                            uint32_t K, uint32_t *maxlen) {
+    __shared__ uint32_t part[1024], pmax[1024];
     const uint32_t tid = threadIdx.x;
-    const uint32_t per = (K + 1023) / 1024;
-    const uint32_t b = tid * per, e = min(K, b + per);
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t b = tid * per, e = min(nblocks, b + per);
     uint32_t sum = 0, mx = 0;
     for (uint32_t k = b; k < e; k++) {
-        uint32_t len = mode ? (in[k + 1] - in[k]) : in[k];
-        mx = max(mx, len);
-        sum += mode ? (len + MSM_CH - 1) / MSM_CH : len;
+        sum += bsum[k];
+        mx = max(mx, bmax[k]);
     }
     part[tid] = sum;
     pmax[tid] = mx;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0;
         uint32_t m = tid >= d ? pmax[tid - d] : 0;
         __syncthreads();
@@ -89,15 +124,41 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t *in, uint
         pmax[tid] = max(pmax[tid], m);
         __syncthreads();
     }
-    uint32_t run = part[tid] - sum;   // exclusive prefix of this thread's segment
+    uint32_t run = part[tid] - sum;
     for (uint32_t k = b; k < e; k++) {
-        uint32_t len = mode ? (in[k + 1] - in[k]) : in[k];
-        out[k] = run;
-        run += mode ? (len + MSM_CH - 1) / MSM_CH : len;
+        uint32_t v = bsum[k];
+        bsum[k] = run;
+        run += v;
     }
     if (tid == 1023) {
         out[K] = part[1023];
         *maxlen = pmax[1023];
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_final_kernel(const uint32_t *in, uint32_t *out, uint32_t K, int mode,
+                                                                    const uint32_t *bsum) {
+    __shared__ uint32_t ssum[SCAN_BLOCK];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * SCAN_TILE + tid * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], sum = 0;
+    for (uint32_t i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t k = base + i;
+        v[i] = k < K ? scan_val(scan_len(in, k, mode), mode) : 0;
+        sum += v[i];
+    }
+    ssum[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < SCAN_BLOCK; d <<= 1) {
+        uint32_t x = tid >= d ? ssum[tid - d] : 0;
+        __syncthreads();
+        ssum[tid] += x;
+        __syncthreads();
+    }
+    uint32_t run = bsum[blockIdx.x] + ssum[tid] - sum;
+    for (uint32_t i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t k = base + i;
+        if (k < K) out[k] = run;
+        run += v[i];
     }
 }
 
@@ -108,8 +169,19 @@ void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_
                         uint32_t *sorted, hipStream_t s) {
     hipLaunchKernelGGL(msm_scatter_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, scalars, n, c, W, off, cursor, sorted);
 }
-void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, hipStream_t s) {
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, s, in, out, K, mode, maxlen);
+// scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
+void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {
+    const uint32_t nblocks = (K + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t *bsum = scratch, *bmax = scratch + nblocks;
+    hipLaunchKernelGGL(msm_scan_partial_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, in, K, mode, bsum, bmax);
+    hipLaunchKernelGGL(msm_scan_top_kernel, dim3(1), dim3(1024), 0, s, bsum, bmax, nblocks, out, K, maxlen);
+    hipLaunchKernelGGL(msm_scan_final_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, in, out, K, mode, bsum);
+}
+size_t msm_scan_scratch_bytes(uint32_t K) { return 8 * (size_t)((K + SCAN_TILE - 1) / SCAN_TILE) + 256; }
+
+int msm_waves_per_simd() {
+    static int w = [] { const char *e = getenv("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
+    return w;
 }
 
 int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);

@@ -16,7 +16,9 @@ constexpr int MSM_THREADS = 128;
 void msm_launch_hist(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt, hipStream_t s);
 void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off, uint32_t *cursor,
                         uint32_t *sorted, hipStream_t s);
-void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, hipStream_t s);
+void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
+size_t msm_scan_scratch_bytes(uint32_t K);
+int msm_waves_per_simd();   // LW_HIP_MSM_WAVES (2 or 3): register budget of the accumulate kernel
 
 // ---------------------------------------------------------------- accumulate
 // Work-item t sums <= CH items of ONE key.
@@ -25,8 +27,8 @@ void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, ui
 //                       empty) -> pout[key], the dense bucket array.
 // from_index: items are point indices into the caller's point array (reference layout); otherwise they are
 // partial sums of the previous round (internal layout).
-template <class C>
-__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_kernel(const void *points, const uint32_t *sorted,
+template <class C, int WAVES>
+__global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *points, const uint32_t *sorted,
                                                                       const Point<C> *pin, const uint32_t *seg_off,
                                                                       const uint32_t *out_off, uint32_t K,
                                                                       uint32_t total_items, Point<C> *pout, int from_index) {
@@ -170,6 +172,7 @@ struct MsmRunner {
         uint32_t *cursor = (uint32_t *)cv.take(4 * (size_t)(K + 1));
         uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
         uint32_t *maxlen_d = (uint32_t *)cv.take(256);
+        uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
         uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
         uint32_t maxlen = maxlen_hint;
         if (!dry) {
@@ -177,7 +180,7 @@ struct MsmRunner {
             hipEvent_t pe = c.prof_begin(stream);
             msm_launch_hist(d_scalars, (uint64_t)n, cbits, W, cnt, stream);
             c.prof_end("msm_hist_kernel", pe, stream);
-            msm_launch_scan(cnt, off, K, 0, maxlen_d, stream);
+            msm_launch_scan(cnt, off, K, 0, maxlen_d, scan_tmp, stream);
             pe = c.prof_begin(stream);
             msm_launch_scatter(d_scalars, (uint64_t)n, cbits, W, off, cursor, sorted, stream);
             c.prof_end("msm_scatter_kernel", pe, stream);
@@ -195,7 +198,7 @@ struct MsmRunner {
             uint64_t out_bound = items_bound / MSM_CH + K;
             Point<C> *pout = (Point<C> *)cv.take(sizeof(Point<C>) * out_bound);
             if (!dry) {
-                msm_launch_scan(seg, out_off, K, 1, maxlen_d, stream);
+                msm_launch_scan(seg, out_off, K, 1, maxlen_d, scan_tmp, stream);
                 uint32_t total = 0;
                 LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
                 LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
@@ -206,8 +209,12 @@ struct MsmRunner {
                 if (total) {
                     const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
                     hipEvent_t pe = c.prof_begin(stream);
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin,
-                                       seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
+                    if (msm_waves_per_simd() == 3)
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted,
+                                           pin, seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
+                    else
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted,
+                                           pin, seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
                     c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
                 }
             }
@@ -221,7 +228,7 @@ struct MsmRunner {
         if (!dry) {
             const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_accumulate_kernel<C>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin, seg,
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin, seg,
                                (const uint32_t *)nullptr, K, K, buckets, from_index ? 1 : 0);
             c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
         }

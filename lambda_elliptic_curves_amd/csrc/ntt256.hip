@@ -81,6 +81,7 @@ struct NttPlan {
 static int g_ntt_cfg = 0;          // 0 = NttCfgA, 1 = NttCfgB, 2 = NttCfgC
 static uint32_t g_ntt_dbg = 0;     // diagnostics: see NttPassParams::dbg (results are wrong when set)
 void ntt_set_debug(uint32_t d) { g_ntt_dbg = d; }
+uint32_t ntt_get_debug() { return g_ntt_dbg; }
 static int cfg_tile_log() { return g_ntt_cfg == 1 ? NttCfgB::TILE_LOG : NttCfgA::TILE_LOG; }
 static int cfg_kmax() { return g_ntt_cfg == 2 ? NttCfgC::KMAX : NttCfgA::KMAX; }
 
@@ -217,6 +218,7 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         NttPassParams p{};
         p.tw = tw;
         p.dbg = g_ntt_dbg;
+        p.lazy_in = (F::LAZY && i > 0) ? 1 : 0;
         p.L = log2n;
         p.s0 = pl.s0[i];
         p.r = pl.r[i];

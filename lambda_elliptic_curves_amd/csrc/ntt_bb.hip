@@ -13,6 +13,8 @@
 
 namespace lw {
 
+uint32_t ntt_get_debug();
+
 constexpr int BB_TILE_LOG = 13;            // 8192 u32 = 32 KiB of LDS
 constexpr int BB_TILE = 1 << BB_TILE_LOG;
 constexpr int BB_THREADS = 256;
@@ -30,6 +32,7 @@ struct BbPassParams {
     uint32_t nsteps;
     uint32_t k[8];
     uint32_t scale, sc;        // N^-1 (R = 2^32 domain) on the last pass of an inverse transform
+    uint32_t dbg;              // diagnostics (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip loads, bit2 skip stores
 };
 
 __device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -76,11 +79,12 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             uint64_t g;
             if (LAST) g = (((((uint64_t)hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + ((uint64_t)m << lgS) + c;
-            x[j] = bb_load_word<W64>(gin, g);
+            x[j] = (p.dbg & 2) ? (uint32_t)g : bb_load_word<W64>(gin, g);
         } else {
             x[j] = lds[(m << logC) | c];
         }
     }
+    if (!(p.dbg & 1))
 #pragma unroll
     for (int u = 0; u < K; u++) {
         const int half = 1 << (K - 1 - u);
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         uint64_t g;
         if (!LAST) g = base + ((uint64_t)m << lgS) + c;
         else g = ((((uint64_t)bb_bitrev(m, r) << (L - r)) + ((uint64_t)b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
-        bb_store_word<W64>(gout, g, lds[e]);
+        if (!(p.dbg & 4)) bb_store_word<W64>(gout, g, lds[e]);
     }
 }
 
@@ -257,6 +261,7 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         p.tw = (const uint32_t *)c.tw[LW_FIELD_BABYBEAR][dir].buf.p;
         p.L = log2n;
         p.lgV = lgV;
+        p.dbg = ntt_get_debug();
         p.s0 = s;
         p.r = base + ((uint32_t)i < extra ? 1 : 0);
         const uint32_t room = BB_TILE_LOG - p.r;

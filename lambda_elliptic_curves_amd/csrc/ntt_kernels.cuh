@@ -49,6 +49,7 @@ struct NttPassParams {
     uint32_t logC;         // log2 columns per tile
     uint32_t nsteps;
     uint32_t k[8];         // stages per register step, sum = r
+    uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
     uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
@@ -134,11 +135,19 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         x[j] = unpack_mem<F>(q0, q1);
     }
 
+    // Lazy reduction (fields with 4+ spare bits, F::LAZY): values ride in [0, 17p) — a butterfly is
+    //   t = w*y in [0,2p) (no final subtraction), x' = x + t, y' = x + 2p - t, so the bound grows by 2p per stage;
+    // a pass has <= 8 stages and fully reduces its input on load (< p, so < 17p at its end); the last pass canonicalises on exit.
+    // Every result is still the unique canonical residue when it leaves the transform, so parity is unaffected.
+    if (F::LAZY && step == 0 && p.lazy_in) {
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = fe_reduce_full(x[j]);
+    }
+
     // stage u of this step == stage s0 + t0 + u of the transform
     if (!(p.dbg & 1))
 #pragma unroll
     for (int u = 0; u < K; u++) {
-        constexpr int dummy = 0; (void)dummy;
         const int half = 1 << (K - 1 - u);
         const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
 #pragma unroll
@@ -147,11 +156,18 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
 #pragma unroll
             for (int jl = 0; jl < half; jl++) {
                 const int j = (jt << (K - u)) | jl;
-                Fe<F> wb = fe_mul<F>(tw, x[j + half]);
-                Fe<F> a = x[j];
-                x[j] = fe_add<F>(a, wb);
-                x[j + half] = fe_sub<F>(a, wb);
-                __builtin_amdgcn_sched_barrier(0);   // keep butterflies serial: 4 interleaved products cost >250 VGPRs
+                if (F::LAZY) {
+                    Fe<F> wb = fe_mul_lazy<F>(tw, x[j + half]);
+                    Fe<F> a = x[j];
+                    x[j] = fe_add_raw<F>(a, wb);
+                    x[j + half] = fe_add2p_sub_raw<F>(a, wb);
+                } else {
+                    Fe<F> wb = fe_mul<F>(tw, x[j + half]);
+                    Fe<F> a = x[j];
+                    x[j] = fe_add<F>(a, wb);
+                    x[j + half] = fe_sub<F>(a, wb);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep butterflies serial: interleaved products cost too many VGPRs
             }
         }
     }
@@ -161,7 +177,13 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
 #pragma unroll
         for (int i = 0; i < 8; i++) sc.v[i] = p.sc[i];
 #pragma unroll
-        for (int j = 0; j < E; j++) x[j] = fe_mul<F>(x[j], sc);
+        for (int j = 0; j < E; j++) {
+            if (F::LAZY) x[j] = fe_cond_sub_kp<F, 0>(fe_mul_lazy<F>(sc, x[j]));   // N^-1 < p: product in [0,2p)
+            else x[j] = fe_mul<F>(x[j], sc);
+        }
+    } else if (F::LAZY && LAST && last_step) {
+#pragma unroll
+        for (int j = 0; j < E; j++) x[j] = fe_reduce_full(x[j]);
     }
 
 #pragma unroll
