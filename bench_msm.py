@@ -55,9 +55,20 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()
     dt = max_over_ranks(dt)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle's restatement of the reference's sequential msm() (pippenger.rs:18-103), one thread
+        Lc = 18
+        sc_c, pts_c = util.msm_case(oid, 1 << Lc, 0x5EED)
+        tc0 = time.perf_counter()
+        O.msm(oid, sc_c, pts_c)
+        dtc = time.perf_counter() - tc0
+        cpu = {"value": adds_ref(1 << Lc) / dtc, "unit": "point-adds/s", "cores": 1, "kind": "port",
+               "sample": "one BLS12-381 G1 msm() of 2^%d points, oracle/lw_oracle.c (sequential Pippenger, reference window "
+                         "rule), %.1f s" % (Lc, dtc), "points_per_s": (1 << Lc) / dtc}
     acc_l = sum(v[0] for k, v in prof.items() if k.startswith("msm_accumulate_kernel"))
     acc_ms = sum(v[1] for k, v in prof.items() if k.startswith("msm_accumulate_kernel"))
-    a_launch = prof.get("msm_accumulate_kernel", (0, 0.0))
+    a_launch = prof.get("msm_accumulate_kernel", prof.get("msm_accumulate_kernel<final>", (0, 0.0)))
     alg_bytes = n * (32 + 144)
     return {
         "metric": "MSM G1 point-adds/sec (BLS12-381, 2^%d points, reference add count adds_ref(N))" % L,
@@ -71,4 +82,5 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
                      "kernel": "msm_accumulate_kernel", "avg_launch_ms": (a_launch[1] / a_launch[0]) if a_launch[0] else None,
                      "note": "whole-MSM algorithmic bytes N*(32+144) over the step time; the MSM is integer-VALU bound by ~2 orders of magnitude"},
         "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
+        "cpu_baseline": cpu,
     }

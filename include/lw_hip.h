@@ -12,6 +12,10 @@
  *                                                (math/src/fft/polynomial.rs:25-68,74-82)
  *   - lw_polynomial_interpolate_fft         <->  Polynomial::interpolate_fft / interpolate_offset_fft
  *                                                (math/src/fft/polynomial.rs:87-127)
+ *   - lw_hip_gen_twiddles                   <->  gen_twiddles (math/src/fft/gpu/cuda/ops.rs:45-66), get_twiddles
+ *                                                (math/src/fft/cpu/roots_of_unity.rs:66-75)
+ *   - lw_hip_bitrev_permutation             <->  bitrev_permutation (math/src/fft/gpu/cuda/ops.rs:68-77),
+ *                                                in_place_bit_reverse_permute (math/src/fft/cpu/bit_reversing.rs:2-9)
  *   - lw_hip_msm / lw_hip_msm_device        <->  msm::pippenger::msm (math/src/msm/pippenger.rs:18-32)
  *   - lw_hip_init / lw_hip_shutdown         <->  CudaState::new (math/src/fft/gpu/cuda/state.rs:29-38); the
  *                                                reference builds and drops device state on every call, this
@@ -121,6 +125,13 @@ int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *i
 int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                       uint32_t log2n, uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null,
                       void *hip_stream);
+
+/* RootsConfig (math/src/field/traits.rs): 0 Natural, 1 NaturalInversed, 2 BitReverse, 3 BitReverseInversed.
+ * Writes 2^order / 2 domain-field elements (host buffer, the layout's base word type).  order > 63 ->
+ * LW_ERR_ORDER_TOO_LARGE; order > TWO_ADICITY -> LW_ERR_ROOT_OF_UNITY; order 0 -> nothing written. */
+int lw_hip_gen_twiddles(lw_field_t field, lw_layout_t layout, uint64_t order, int config, void *out);
+/* out[i] = in[bitrev(i)] over n = 2^k elements of the layout (host buffers, may alias). */
+int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *in, void *out, size_t n);
 
 /* Cross-shard step of the multi-GPU NTT (no reference counterpart: the reference has no multi-device path).
  * A 2^log2n_total vector is block-distributed over G = 2^log2_shards GPUs (M = N/G elements each).  After the

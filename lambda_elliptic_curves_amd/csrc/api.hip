@@ -120,6 +120,9 @@ int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t 
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
 
+int gen_twiddles_device(Context &c, lw_field_t field, lw_layout_t layout, uint32_t order, int config, void *d_out, hipStream_t stream);
+int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream);
+
 static uint32_t two_adicity(lw_field_t f) {
     switch (f) {
         case LW_FIELD_STARK252: return Stark252::TWO_ADICITY;
@@ -302,6 +305,52 @@ int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const 
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.ntt_calls++;
     return rc;
+}
+
+// gen_twiddles (math/src/fft/gpu/cuda/ops.rs:45-66 -> math/src/fft/cpu/roots_of_unity.rs:66-75)
+int lw_hip_gen_twiddles(lw_field_t field, lw_layout_t layout, uint64_t order, int config, void *out) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (order > 63) { set_error("Order should be less than or equal to 63, but is %llu", (unsigned long long)order); return LW_ERR_ORDER_TOO_LARGE; }
+    if (config < 0 || config > 3) { set_error("bad roots config %d", config); return LW_ERR_BAD_ARG; }
+    if (order > two_adicity(field)) { set_error("no primitive 2^%llu-th root of unity in this field", (unsigned long long)order); return LW_ERR_ROOT_OF_UNITY; }
+    const uint64_t count = (1ull << order) / 2;
+    if (count == 0) return LW_OK;
+    if (!out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    rc = ensure_init();
+    if (rc) return rc;
+    // twiddles live in the domain field: one base word per entry for every BabyBear shape
+    const size_t eb = field == LW_FIELD_BABYBEAR ? (layout == LW_LAYOUT_BABYBEAR_U32_R32 ? 4 : 8) : 32;
+    if (c.host_io_b.ensure(count * eb)) return LW_ERR_ALLOC;
+    rc = gen_twiddles_device(c, field, layout, (uint32_t)order, config, c.host_io_b.p, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, count * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+// bitrev_permutation (math/src/fft/gpu/cuda/ops.rs:68-77): out[i] = in[bitrev(i)]; in may alias out
+int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *in, void *out, size_t n) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (n == 0) return LW_OK;
+    if (n & (n - 1)) { set_error("Input length is %zu, which is not a power of two", n); return LW_ERR_INPUT_NOT_POW2; }
+    if (!in || !out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+    uint32_t log2n = 0;
+    while (((size_t)1 << log2n) < n) log2n++;
+    if (log2n > 32) { set_error("2^%u elements exceed device memory", log2n); return LW_ERR_ALLOC; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    rc = ensure_init();
+    if (rc) return rc;
+    const size_t eb = lw_hip_field_elem_bytes(field, layout);
+    if (c.host_io_a.ensure(n * eb) || c.host_io_b.ensure(n * eb)) return LW_ERR_ALLOC;
+    LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, in, n * eb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    rc = bitrev_device(eb, c.host_io_a.p, c.host_io_b.p, log2n, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, n * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    return LW_OK;
 }
 
 int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,

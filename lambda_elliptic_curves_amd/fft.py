@@ -86,6 +86,28 @@ def interpolate_offset_fft(field, fft_evals, offset):
     return interpolate_fft(field, fft_evals, offset)
 
 
+# RootsConfig (math/src/field/traits.rs)
+ROOTS_NATURAL, ROOTS_NATURAL_INVERSED, ROOTS_BIT_REVERSE, ROOTS_BIT_REVERSE_INVERSED = 0, 1, 2, 3
+
+
+def get_twiddles(field, order, config):
+    """roots_of_unity::get_twiddles / the CUDA seam's gen_twiddles: 2^order / 2 powers of the primitive 2^order-th
+    root (or its inverse), natural or bit-reversed, as domain-field elements."""
+    count = (1 << order) // 2 if order <= 63 else 0
+    base_words = field.words if field.layout == L.LAYOUT_U64_LIMBS_MS_FIRST else 1
+    out = np.empty((count,) if base_words == 1 else (count, base_words), dtype=field.dtype)
+    check(L.lib().lw_hip_gen_twiddles(field.field, field.layout, order, config, _ptr(out) if count else None))
+    return out
+
+
+def bitrev_permutation(field, data):
+    """in_place_bit_reverse_permute / the CUDA seam's bitrev_permutation (returns a new array)."""
+    a = _as_elems(field, data)
+    out = np.empty_like(a)
+    check(L.lib().lw_hip_bitrev_permutation(field.field, field.layout, _ptr(a), _ptr(out), a.shape[0]))
+    return out
+
+
 def ntt(field, data, inverse=False, log2n=None, batch=1, batch_stride=0, offset=None):
     """Backend seam on host buffers (evaluate_fft_cuda / interpolate_fft_cuda equivalents,
     math/src/fft/gpu/cuda/polynomial.rs:16-49): the slice is already power-of-two sized."""

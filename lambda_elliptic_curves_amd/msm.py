@@ -34,6 +34,15 @@ def msm(curve, cs, points):
     return out
 
 
+def msm_with(curve, cs, points, window_size):
+    """pippenger::msm_with (math/src/msm/pippenger.rs:42-103).  The window only shapes the reference's schedule;
+    the group element is the same for every window, so this is msm() (the device picks its own window)."""
+    if len(np.asarray(cs).reshape(-1, 4)) != len(np.asarray(points).reshape(-1, curve.point_words)):
+        from .errors import LengthMismatch
+        raise LengthMismatch("scalars and points have different lengths")
+    return msm(curve, cs, points)
+
+
 def msm_device(curve, t_scalars, t_points, n, stream=None):
     """Device-resident MSM on torch tensors; returns the projective result as a numpy array."""
     import torch

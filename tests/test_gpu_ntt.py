@@ -142,3 +142,24 @@ def test_device_resident_matches_host_path_and_large_roundtrip():
         torch.cuda.synchronize()
         assert np.array_equal(t_out.cpu().numpy().view(np.uint64), a)
         # linearity spot check: NTT(a)[0] = sum(a)  <=> inverse of constant... (checked via oracle at 2^12 only)
+
+
+@pytest.mark.parametrize("name", ["stark252", "fr381", "babybear_u32", "babybear_u64"])
+def test_gen_twiddles_and_bitrev_permutation_match_oracle(name):
+    # the other two ops of the reference's GPU seam (math/src/fft/gpu/cuda/ops.rs:45-77; fuzz twiddles_generation_diff)
+    from lambda_elliptic_curves_amd import errors, fft
+    fld, oid = util.field_pairs()[name]
+    for order in (0, 1, 2, 5, 11, 17):
+        for cfg, ocfg in ((fft.ROOTS_NATURAL, O.ROOTS_NATURAL), (fft.ROOTS_NATURAL_INVERSED, O.ROOTS_NATURAL_INV),
+                          (fft.ROOTS_BIT_REVERSE, O.ROOTS_BITREV), (fft.ROOTS_BIT_REVERSE_INVERSED, O.ROOTS_BITREV_INV)):
+            got = fft.get_twiddles(fld, order, cfg)
+            exp = O.get_twiddles(oid, order, ocfg)
+            assert got.size == exp.size and np.array_equal(got.reshape(-1), exp.reshape(-1))
+    with pytest.raises(errors.OrderError):     # roots_of_unity.rs:70-72
+        fft.get_twiddles(fld, 64, fft.ROOTS_NATURAL)
+    for log_n in (0, 1, 4, 13):
+        a = util.rand_elems(name, 1 << log_n, 31 + log_n)
+        got = fft.bitrev_permutation(fld, a)
+        assert np.array_equal(got.reshape(-1), O.bit_reverse_permute(oid, a).reshape(-1))
+    with pytest.raises(errors.InputError):
+        fft.bitrev_permutation(fld, util.rand_elems(name, 3, 1))
