@@ -32,34 +32,106 @@ __device__ __forceinline__ uint32_t scalar_digit(const uint32_t *s, uint32_t w, 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
-__global__ void msm_hist_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s[8];
+// ---- bucket scatter: two-level counting sort of (point index) by key = (window, digit) ----------------------
+// Level A partitions the N*W items into coarse bins (window, high digit bits) with workgroup-local LDS histograms:
+// a workgroup counts its items per coarse bin, reserves one contiguous run per bin with a single global atomic,
+// and writes its items of that bin into the run (ranks inside the run come from LDS atomics), so global traffic is
+// runs, not scattered 4-byte stores.  Level B gives every coarse bin to one workgroup, which counting-sorts it by
+// the low 8 digit bits entirely through LDS, and emits the per-key offsets the accumulation needs.
+constexpr uint32_t SORT_FINE_BITS = 8;
+constexpr uint32_t SORT_PTS_PER_BLOCK = 1024;   // points per level-A workgroup (x W windows items)
+constexpr uint32_t SORT_THREADS = 256;
+constexpr uint32_t SORT_MAX_COARSE = 4096;      // W << (c - 8) <= 16 << 8
+
+__device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint64_t i, uint32_t *s) {
     const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t d = scalar_digit(s, w, c);
-        if (d) atomicAdd(&cnt[(w << c) + d], 1u);
+}
+
+// pass A0 (ITEMS == nullptr): coarse histogram.  pass A1: scatter packed items (fine digit << 32 | index) into runs.
+__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W,
+                                                                 uint32_t fine_bits, uint32_t *coarse_cnt,
+                                                                 const uint32_t *coarse_off, uint32_t *coarse_cursor,
+                                                                 uint64_t *items) {
+    __shared__ uint32_t h[SORT_MAX_COARSE];
+    __shared__ uint32_t base[SORT_MAX_COARSE];
+    const uint32_t hb = c - fine_bits, CB = W << hb;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < CB; b += SORT_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint64_t p0 = (uint64_t)blockIdx.x * SORT_PTS_PER_BLOCK;
+    const uint64_t p1 = min(n, p0 + SORT_PTS_PER_BLOCK);
+    for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
+        uint32_t s[8];
+        load_scalar_words(scalars, i, s);
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = scalar_digit(s, w, c);
+            if (d) atomicAdd(&h[(w << hb) | (d >> fine_bits)], 1u);
+        }
+    }
+    __syncthreads();
+    if (!items) {
+        for (uint32_t b = tid; b < CB; b += SORT_THREADS)
+            if (h[b]) atomicAdd(&coarse_cnt[b], h[b]);
+        return;
+    }
+    for (uint32_t b = tid; b < CB; b += SORT_THREADS) {
+        uint32_t cnt = h[b];
+        base[b] = cnt ? coarse_off[b] + atomicAdd(&coarse_cursor[b], cnt) : 0;
+        h[b] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
+        uint32_t s[8];
+        load_scalar_words(scalars, i, s);
+        for (uint32_t w = 0; w < W; w++) {
+            uint32_t d = scalar_digit(s, w, c);
+            if (d) {
+                uint32_t b = (w << hb) | (d >> fine_bits);
+                uint32_t r = atomicAdd(&h[b], 1u);
+                items[base[b] + r] = ((uint64_t)(d & ((1u << fine_bits) - 1)) << 32) | (uint32_t)i;
+            }
+        }
     }
 }
 
-__global__ void msm_scatter_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off,
-                                   uint32_t *cursor, uint32_t *sorted) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s[8];
-    const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
-    uint4 a = q[0], b = q[1];
-    s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t d = scalar_digit(s, w, c);
-        if (d) {
-            uint32_t key = (w << c) + d;
-            uint32_t pos = off[key] + atomicAdd(&cursor[key], 1u);
-            sorted[pos] = (uint32_t)i;
-        }
+// pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const uint64_t *items, const uint32_t *coarse_off, uint32_t fine_bits,
+                                                               uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen) {
+    __shared__ uint32_t h[1 << SORT_FINE_BITS];
+    __shared__ uint32_t pre[1 << SORT_FINE_BITS];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x, FB = 1u << fine_bits;
+    const uint32_t i0 = coarse_off[b], i1 = coarse_off[b + 1];
+    if (tid < FB) h[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = i0 + tid; i < i1; i += SORT_THREADS) atomicAdd(&h[(uint32_t)(items[i] >> 32)], 1u);
+    __syncthreads();
+    // exclusive scan of the FB (<= 256) counts
+    uint32_t v = tid < FB ? h[tid] : 0;
+    pre[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        uint32_t x = tid >= d ? pre[tid - d] : 0;
+        __syncthreads();
+        pre[tid] += x;
+        __syncthreads();
+    }
+    const uint32_t excl = pre[tid] - v;
+    if (tid < FB) {
+        off[(b << fine_bits) | tid] = i0 + excl;
+        if (v) atomicMax(maxlen, v);
+    }
+    if (b == gridDim.x - 1 && tid == 0) off[K] = i1;
+    __syncthreads();
+    if (tid < FB) {
+        pre[tid] = i0 + excl;   // running cursor per fine digit
+    }
+    __syncthreads();
+    for (uint32_t i = i0 + tid; i < i1; i += SORT_THREADS) {
+        uint64_t it = items[i];
+        uint32_t pos = atomicAdd(&pre[(uint32_t)(it >> 32)], 1u);
+        sorted[pos] = (uint32_t)it;
     }
 }
 
@@ -162,12 +234,30 @@ __global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_final_kernel(const uint32
     }
 }
 
-void msm_launch_hist(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt, hipStream_t s) {
-    hipLaunchKernelGGL(msm_hist_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, scalars, n, c, W, cnt);
+uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W) {
+    const uint32_t fine = c < SORT_FINE_BITS ? c : SORT_FINE_BITS;
+    return W << (c - fine);
 }
-void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off, uint32_t *cursor,
-                        uint32_t *sorted, hipStream_t s) {
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, scalars, n, c, W, off, cursor, sorted);
+// coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off: CB + 1; items: n*W u64; off: K + 1; maxlen: zeroed
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
+                     uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
+                     uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
+    const uint32_t fine = cb < SORT_FINE_BITS ? cb : SORT_FINE_BITS;
+    const uint32_t CB = W << (cb - fine);
+    const uint32_t blocks = (uint32_t)((n + SORT_PTS_PER_BLOCK - 1) / SORT_PTS_PER_BLOCK);
+    hipEvent_t pe = c.prof_begin(s);
+    hipLaunchKernelGGL(msm_coarse_kernel, dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, coarse_cnt,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
+    c.prof_end("msm_coarse_kernel<count>", pe, s);
+    msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL(msm_coarse_kernel, dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, coarse_cnt,
+                       (const uint32_t *)coarse_off, coarse_cursor, items);
+    c.prof_end("msm_coarse_kernel<scatter>", pe, s);
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL(msm_fine_kernel, dim3(CB), dim3(SORT_THREADS), 0, s, (const uint64_t *)items, (const uint32_t *)coarse_off,
+                       fine, sorted, off, K, maxlen);
+    c.prof_end("msm_fine_kernel", pe, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {

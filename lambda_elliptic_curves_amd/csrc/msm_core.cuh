@@ -13,9 +13,10 @@ constexpr uint32_t MSM_G_LOG = 4;      // buckets per running-sum group (2^4): s
 constexpr int MSM_THREADS = 128;
 
 // host launchers for the curve-independent kernels (defined in msm.hip)
-void msm_launch_hist(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, uint32_t *cnt, hipStream_t s);
-void msm_launch_scatter(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W, const uint32_t *off, uint32_t *cursor,
-                        uint32_t *sorted, hipStream_t s);
+uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W);
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
+                     uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
+                     uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
 size_t msm_scan_scratch_bytes(uint32_t K);
 int msm_waves_per_simd();   // LW_HIP_MSM_WAVES (2 or 3): register budget of the accumulate kernel
@@ -168,22 +169,21 @@ struct MsmRunner {
                  uint32_t maxlen_hint) {
         const uint32_t K = W << cbits;
         const bool dry = cv.base == nullptr;
-        uint32_t *cnt = (uint32_t *)cv.take(4 * (size_t)(K + 1));
-        uint32_t *cursor = (uint32_t *)cv.take(4 * (size_t)(K + 1));
-        uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
+        const uint32_t CB = msm_sort_coarse_bins(cbits, W);
+        uint32_t *coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
+        uint32_t *coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *maxlen_d = (uint32_t *)cv.take(256);
+        uint32_t *coarse_off = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
+        uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
         uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
         uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
+        uint64_t *items = (uint64_t *)cv.take(8 * n * W);
         uint32_t maxlen = maxlen_hint;
         if (!dry) {
-            LW_HIP_CHECK(hipMemsetAsync(cnt, 0, 8 * (size_t)(K + 1) + 512, stream), LW_ERR_LAUNCH);   // cnt + cursor
-            hipEvent_t pe = c.prof_begin(stream);
-            msm_launch_hist(d_scalars, (uint64_t)n, cbits, W, cnt, stream);
-            c.prof_end("msm_hist_kernel", pe, stream);
-            msm_launch_scan(cnt, off, K, 0, maxlen_d, scan_tmp, stream);
-            pe = c.prof_begin(stream);
-            msm_launch_scatter(d_scalars, (uint64_t)n, cbits, W, off, cursor, sorted, stream);
-            c.prof_end("msm_scatter_kernel", pe, stream);
+            // coarse_cnt, coarse_cursor and maxlen are adjacent carve-outs: one memset clears all three
+            LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
+            msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
+                            maxlen_d, scan_tmp, stream);
             LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
         }
@@ -245,6 +245,10 @@ struct MsmRunner {
             }
             const uint32_t cbits = pick_window(n);
             W = (256 + cbits - 1) / cbits;
+            if (((uint64_t)n * W) >> 32) {
+                set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
+                return LW_ERR_BAD_ARG;
+            }
             // size the workspace for the worst case (one bucket holding every point)
             Carver dry{nullptr, 0};
             Point<C> *S_d = nullptr;
