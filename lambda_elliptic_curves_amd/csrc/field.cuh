@@ -350,6 +350,17 @@ __device__ __forceinline__ void col_mp(uint64_t &lo, uint32_t &hi, const uint32_
         col_mp<F, K, I + 1, IEND>(lo, hi, m);
     }
 }
+#include "mac_chains.inc"
+
+// every limb of p in [LO, HI) is a literal (> 64, so not an inline constant and not zero): the whole m*p part of a
+// column can be one statement with SGPR operands
+template <class F, int LO, int HI>
+constexpr bool lw_all_literal() {
+    for (int i = LO; i < HI; i++)
+        if (F::p(i) <= 64) return false;
+    return true;
+}
+
 // column K, first chunk: acc = init + a[I]*b[K-I] + ...; returns via lo/hi, continues with col_ab
 template <class F, int K, int I, int IEND>
 __device__ __forceinline__ void col_ab_first(uint64_t &lo, uint32_t &hi, uint64_t init, const Fe<F> &a, const Fe<F> &b) {
@@ -373,16 +384,18 @@ __device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe
         uint64_t lo;
         uint32_t hi;
         if constexpr (K < N) {
-            col_ab_first<F, K, 0, K + 1>(lo, hi, init, a, b);
-            col_mp<F, K, 0, K>(lo, hi, m);
+            col_ab_first_dispatch<F, K, 0, K + 1>(lo, hi, init, a, b);
+            if constexpr (K >= 1 && lw_all_literal<F, 1, K + 1>()) col_mp_dispatch<F, K, 0, K>(lo, hi, m);
+            else col_mp<F, K, 0, K>(lo, hi, m);
             uint32_t mk;
             if constexpr (F::INV == 0xffffffffu) mk = 0u - (uint32_t)lo;
             else mk = (uint32_t)lo * F::INV;
             m[K] = mk;
             mac96_c1<F::p(0)>(lo, hi, mk);
         } else {
-            col_ab_first<F, K, K - N + 1, N>(lo, hi, init, a, b);
-            col_mp<F, K, K - N + 1, N>(lo, hi, m);
+            col_ab_first_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, init, a, b);
+            if constexpr (lw_all_literal<F, K - N + 1, N>()) col_mp_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, m);
+            else col_mp<F, K, K - N + 1, N>(lo, hi, m);
             t[K - N] = (uint32_t)lo;
         }
         fips_col<F, K + 1>((lo >> 32) | ((uint64_t)hi << 32), a, b, m, t);

@@ -29,7 +29,7 @@ struct NttCfg {
     static constexpr int THREADS = THREADS_;
     static constexpr int KMAX = KMAX_;
     // workgroups per CU by LDS, waves per SIMD that follow (launch bound for the register allocator)
-    static constexpr int WG_PER_CU = (160 * 1024) / (TILE * 32) > 8 ? 8 : (160 * 1024) / (TILE * 32);
+    static constexpr int WG_PER_CU = (160 * 1024) / (TILE * 32 + 8192) > 8 ? 8 : (160 * 1024) / (TILE * 32 + 8192);   // + staged twiddles
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * THREADS / 256) > 8 ? 8 : (WG_PER_CU * THREADS / 256) < 1 ? 1 : (WG_PER_CU * THREADS / 256);
 };
 using NttCfgA = NttCfg<11, 512, 2>;   // 64 KiB tile, 2 workgroups/CU, 4 waves/SIMD
@@ -89,7 +89,7 @@ __device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
 
 // One work-item: 2^K elements, K stages in registers.
 template <class F, int K, bool LAST, int TILE>
-__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], const uint4 *gin,
+__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], const uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
@@ -152,7 +152,15 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
 #pragma unroll
         for (int jt = 0; jt < (1 << u); jt++) {
-            Fe<F> tw = tw_load<F>(p.tw, gt | (uint32_t)jt);
+            Fe<F> tw;
+            if (LAST) {
+                tw = tw_load<F>(p.tw, gt | (uint32_t)jt);
+            } else {   // this tile's 2^r - 1 twiddles were staged in LDS: stage t, group x -> slot 2^t - 1 + x
+                const uint32_t li = (1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt);
+                uint4 a = ltw[0][li], b = ltw[1][li];
+                tw.v[0] = a.x; tw.v[1] = a.y; tw.v[2] = a.z; tw.v[3] = a.w;
+                tw.v[4] = b.x; tw.v[5] = b.y; tw.v[6] = b.z; tw.v[7] = b.w;
+            }
 #pragma unroll
             for (int jl = 0; jl < half; jl++) {
                 const int j = (jt << (K - u)) | jl;
@@ -203,6 +211,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
     constexpr int NTT_KMAX = CFG::KMAX;
     constexpr int NTT_TILE = CFG::TILE;
     __shared__ uint4 lds[2][NTT_TILE];
+    __shared__ uint4 ltw[LAST ? 1 : 2][LAST ? 1 : 256];   // non-last passes: the tile's twiddles (<= 255 x 32 B)
     const uint32_t tid = threadIdx.x;
     const uint32_t r = p.r, logC = p.logC, L = p.L;
     const uint32_t tile_log = r + logC;
@@ -222,6 +231,16 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         hi_low = bitrev_bits(b, L - r - logC);
     }
 
+    if (!LAST) {
+        // stage t of the pass uses T[(hi << t) | x], x < 2^t, shared by every column of the tile
+        for (uint32_t i = tid; i + 1 < (1u << r); i += NTT_THREADS) {
+            const uint32_t t = 31 - __clz(i + 1), x = i + 1 - (1u << t);
+            const uint64_t g = ((uint64_t)hi_uniform << t) | x;
+            ltw[0][i] = p.tw[2 * g];
+            ltw[1][i] = p.tw[2 * g + 1];
+        }
+        __syncthreads();
+    }
     uint32_t t0 = 0;
     for (uint32_t step = 0; step < p.nsteps; step++) {
         const uint32_t k = p.k[step];
@@ -229,9 +248,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
-            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
         }
         t0 += k;
     }
