@@ -164,13 +164,17 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
 #pragma unroll
             for (int jl = 0; jl < half; jl++) {
                 const int j = (jt << (K - u)) | jl;
+                // T[0] = 1: the first group of every stage multiplies by one (2^-t of stage t's butterflies, i.e. a
+                // quarter of the first pass's products).  The reference multiplies anyway (fft.rs:40-43); the product
+                // by the Montgomery one is the identity on canonical residues, so skipping it changes no byte.
+                const bool unit = (jt == 0) && (gt == 0);
                 if (F::LAZY) {
-                    Fe<F> wb = fe_mul_lazy<F>(tw, x[j + half]);
+                    Fe<F> wb = unit ? fe_reduce_full(x[j + half]) : fe_mul_lazy<F>(tw, x[j + half]);
                     Fe<F> a = x[j];
                     x[j] = fe_add_raw<F>(a, wb);
                     x[j + half] = fe_add2p_sub_raw<F>(a, wb);
                 } else {
-                    Fe<F> wb = fe_mul<F>(tw, x[j + half]);
+                    Fe<F> wb = unit ? x[j + half] : fe_mul<F>(tw, x[j + half]);
                     Fe<F> a = x[j];
                     x[j] = fe_add<F>(a, wb);
                     x[j + half] = fe_sub<F>(a, wb);
