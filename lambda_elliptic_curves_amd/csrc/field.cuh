@@ -384,18 +384,28 @@ __device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe
         uint64_t lo;
         uint32_t hi;
         if constexpr (K < N) {
+#if defined(LW_NO_COLUMN_CHAINS)
+            col_ab_first<F, K, 0, K + 1>(lo, hi, init, a, b);
+            col_mp<F, K, 0, K>(lo, hi, m);
+#else
             col_ab_first_dispatch<F, K, 0, K + 1>(lo, hi, init, a, b);
             if constexpr (K >= 1 && lw_all_literal<F, 1, K + 1>()) col_mp_dispatch<F, K, 0, K>(lo, hi, m);
             else col_mp<F, K, 0, K>(lo, hi, m);
+#endif
             uint32_t mk;
             if constexpr (F::INV == 0xffffffffu) mk = 0u - (uint32_t)lo;
             else mk = (uint32_t)lo * F::INV;
             m[K] = mk;
             mac96_c1<F::p(0)>(lo, hi, mk);
         } else {
+#if defined(LW_NO_COLUMN_CHAINS)
+            col_ab_first<F, K, K - N + 1, N>(lo, hi, init, a, b);
+            col_mp<F, K, K - N + 1, N>(lo, hi, m);
+#else
             col_ab_first_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, init, a, b);
             if constexpr (lw_all_literal<F, K - N + 1, N>()) col_mp_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, m);
             else col_mp<F, K, K - N + 1, N>(lo, hi, m);
+#endif
             t[K - N] = (uint32_t)lo;
         }
         fips_col<F, K + 1>((lo >> 32) | ((uint64_t)hi << 32), a, b, m, t);

@@ -22,17 +22,23 @@ size_t msm_scan_scratch_bytes(uint32_t K);
 int msm_waves_per_simd();   // LW_HIP_MSM_WAVES (2 or 3): register budget of the accumulate kernel
 
 // ---------------------------------------------------------------- accumulate
+// All device point arrays (caller's points, partial sums, buckets, running-sum temporaries) use the reference
+// memory layout, so one load path serves every round.
+template <class C>
+__device__ __forceinline__ Point<C> pt_ld(const void *base, size_t i) { return pt_load<C>((const char *)base + i * (3 * C::B::BYTES)); }
+template <class C>
+__device__ __forceinline__ void pt_st(void *base, size_t i, const Point<C> &p) { pt_store<C>((char *)base + i * (3 * C::B::BYTES), p); }
+
 // Work-item t sums <= CH items of ONE key.
 //   out_off != nullptr: t is a (key, piece) pair found by binary search in out_off; result -> pout[t]
 //   out_off == nullptr: last round, every key has <= CH items; t is the key; result (identity when the key is
 //                       empty) -> pout[key], the dense bucket array.
-// from_index: items are point indices into the caller's point array (reference layout); otherwise they are
-// partial sums of the previous round (internal layout).
+// index != nullptr: item i is the point pts[index[i]] (first round: the caller's points through the sorted index
+// list); otherwise item i is pts[i] (partial sums of the previous round).
 template <class C, int WAVES>
-__global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *points, const uint32_t *sorted,
-                                                                      const Point<C> *pin, const uint32_t *seg_off,
-                                                                      const uint32_t *out_off, uint32_t K,
-                                                                      uint32_t total_items, Point<C> *pout, int from_index) {
+__global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *pts, const uint32_t *index,
+                                                                             const uint32_t *seg_off, const uint32_t *out_off,
+                                                                             uint32_t K, uint32_t total_items, void *pout) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total_items) return;
     uint32_t b, e;
@@ -48,20 +54,31 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
         b = seg_off[t];
         e = seg_off[t + 1];
     }
-    constexpr size_t PB = 3 * C::B::BYTES;
+    // The gather of a point (144-288 B from a random row) is a dependent chain index -> row.  The next index is
+    // fetched one addition ahead, and the next row's cache lines are touched (one dword per 128 B, discarded) before
+    // the current addition starts, so the real load at the top of the next iteration hits L2.
     Point<C> acc = pt_identity<C>();
+    uint32_t idx_next = b;
     if (b < e) {
-        if (from_index) acc = pt_load<C>((const char *)points + (size_t)sorted[b] * PB);
-        else acc = pin[b];
+        acc = pt_ld<C>(pts, index ? index[b] : b);
+        if (b + 1 < e) idx_next = index ? index[b + 1] : b + 1;
     }
+    constexpr int PW = 3 * C::B::BYTES / 4;
 #pragma nounroll
     for (uint32_t i = b + 1; i < e; i++) {
-        Point<C> p;
-        if (from_index) p = pt_load<C>((const char *)points + (size_t)sorted[i] * PB);
-        else p = pin[i];
+        Point<C> p = pt_ld<C>(pts, idx_next);
+        uint32_t touch0 = 0, touch1 = 0, touch2 = 0;
+        if (i + 1 < e) {
+            idx_next = index ? index[i + 1] : i + 1;
+            const uint32_t *row = reinterpret_cast<const uint32_t *>((const char *)pts + (size_t)idx_next * (PW * 4));
+            touch0 = row[0];
+            touch1 = row[32 < PW ? 32 : 0];
+            touch2 = row[PW - 1];
+        }
         acc = pt_add<C>(acc, p);
+        asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // consume the touches after the MACs
     }
-    pout[t] = acc;
+    pt_st<C>(pout, t, acc);
 }
 
 // ---------------------------------------------------------------- bucket reduce
@@ -70,34 +87,33 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
 // out is laid out [2*nwin][ngroups]: rows 0..nwin-1 hold A, rows nwin..2*nwin-1 hold Q, so the next level
 // reduces both families in one launch.
 template <class C>
-__global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const Point<C> *in, uint32_t n, uint32_t g,
-                                                                     uint32_t ngroups, uint32_t nwin, Point<C> *out) {
+__global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const void *in, uint32_t n, uint32_t g,
+                                                                     uint32_t ngroups, uint32_t nwin, void *out) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= ngroups) return;
     const uint32_t w = blockIdx.y;
-    const Point<C> *base = in + (size_t)w * n;
+    const size_t base = (size_t)w * n;
     const uint32_t d0 = j * g, d1 = min(n, d0 + g);
     Point<C> running = pt_identity<C>(), q = pt_identity<C>();
 #pragma nounroll
     for (uint32_t d = d1; d-- > d0;) {
         q = pt_add<C>(q, running);
-        running = pt_add<C>(running, base[d]);
+        running = pt_add<C>(running, pt_ld<C>(in, base + d));
     }
-    out[(size_t)w * ngroups + j] = running;
-    out[(size_t)(nwin + w) * ngroups + j] = q;
+    pt_st<C>(out, (size_t)w * ngroups + j, running);
+    pt_st<C>(out, (size_t)(nwin + w) * ngroups + j, q);
 }
 
 // Level results (one point per array, rows as above) -> S[w] = sumQ[w] + 2^k * S(A)[w],  A[w] = sumA[w]
 template <class C>
-__global__ void msm_combine_kernel(const Point<C> *S2, const Point<C> *A2, uint32_t k, uint32_t nwin, Point<C> *S,
-                                   Point<C> *A) {
+__global__ void msm_combine_kernel(const void *S2, const void *A2, uint32_t k, uint32_t nwin, void *S, void *A) {
     uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwin) return;
-    Point<C> x = S2[w];
+    Point<C> x = pt_ld<C>(S2, w);
 #pragma nounroll
     for (uint32_t i = 0; i < k; i++) x = pt_dbl<C>(x);
-    S[w] = pt_add<C>(A2[nwin + w], x);
-    A[w] = A2[w];
+    pt_st<C>(S, w, pt_add<C>(pt_ld<C>(A2, nwin + w), x));
+    pt_st<C>(A, w, pt_ld<C>(A2, w));
 }
 
 // ---------------------------------------------------------------- host orchestration
@@ -128,35 +144,35 @@ struct MsmRunner {
     uint32_t W;
 
     // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
-    int reduce(const Point<C> *in, uint32_t n, uint32_t nwin, Carver &cv, Point<C> **S_out, Point<C> **A_out) {
+    static constexpr size_t PB = 3 * C::B::BYTES;
+    int reduce(const char *in, uint32_t n, uint32_t nwin, Carver &cv, char **S_out, char **A_out) {
         const uint32_t g = 1u << MSM_G_LOG;
         if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
-            Point<C> *out = (Point<C> *)cv.take(sizeof(Point<C>) * 2 * (size_t)nwin);
+            char *out = (char *)cv.take(PB * 2 * (size_t)nwin);
             if (cv.base) {
                 hipEvent_t pe = c.prof_begin(stream);
-                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, nwin), dim3(64), 0, stream, in, n, n, 1u, nwin, out);
+                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, nwin), dim3(64), 0, stream, (const void *)in, n, n, 1u, nwin, (void *)out);
                 c.prof_end("msm_group_sum_kernel", pe, stream);
             }
             *A_out = out;
-            *S_out = out ? out + nwin : nullptr;
-            if (!cv.base) *S_out = nullptr;
+            *S_out = cv.base ? out + PB * nwin : nullptr;
             return LW_OK;
         }
         const uint32_t ng = (n + g - 1) / g;
-        Point<C> *lvl = (Point<C> *)cv.take(sizeof(Point<C>) * 2 * (size_t)nwin * ng);
+        char *lvl = (char *)cv.take(PB * 2 * (size_t)nwin * ng);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
             hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((ng + MSM_THREADS - 1) / MSM_THREADS, nwin), dim3(MSM_THREADS), 0,
-                               stream, in, n, g, ng, nwin, lvl);
+                               stream, (const void *)in, n, g, ng, nwin, (void *)lvl);
             c.prof_end("msm_group_sum_kernel", pe, stream);
         }
-        Point<C> *S2, *A2;
+        char *S2, *A2;
         int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2);
         if (rc) return rc;
-        Point<C> *S = (Point<C> *)cv.take(sizeof(Point<C>) * nwin), *A = (Point<C> *)cv.take(sizeof(Point<C>) * nwin);
+        char *S = (char *)cv.take(PB * nwin), *A = (char *)cv.take(PB * nwin);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, S2, A2, MSM_G_LOG, nwin, S, A);
+            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2, MSM_G_LOG, nwin, (void *)S, (void *)A);
             c.prof_end("msm_combine_kernel", pe, stream);
         }
         *S_out = S;
@@ -165,7 +181,7 @@ struct MsmRunner {
     }
 
     // one pass over the pipeline; with cv.base == nullptr it only measures the workspace
-    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, Point<C> **S_out,
+    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, char **S_out,
                  uint32_t maxlen_hint) {
         const uint32_t K = W << cbits;
         const bool dry = cv.base == nullptr;
@@ -189,14 +205,14 @@ struct MsmRunner {
         }
         // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
         const uint32_t *seg = off;
-        const Point<C> *pin = nullptr;
-        bool from_index = true;
+        const void *pts = d_points;         // first round: the caller's points through the sorted index list
+        const uint32_t *index = sorted;
         uint64_t len = maxlen;             // longest segment
         uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
         while (len > MSM_CH) {
             uint32_t *out_off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
             uint64_t out_bound = items_bound / MSM_CH + K;
-            Point<C> *pout = (Point<C> *)cv.take(sizeof(Point<C>) * out_bound);
+            char *pout = (char *)cv.take(PB * out_bound);
             if (!dry) {
                 msm_launch_scan(seg, out_off, K, 1, maxlen_d, scan_tmp, stream);
                 uint32_t total = 0;
@@ -209,30 +225,26 @@ struct MsmRunner {
                 if (total) {
                     const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
                     hipEvent_t pe = c.prof_begin(stream);
-                    if (msm_waves_per_simd() == 3)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted,
-                                           pin, seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
-                    else
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted,
-                                           pin, seg, (const uint32_t *)out_off, K, total, pout, from_index ? 1 : 0);
-                    c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
+                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                       (const uint32_t *)out_off, K, total, (void *)pout);
+                    c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
                 }
             }
             seg = out_off;
-            pin = pout;
-            from_index = false;
+            pts = pout;
+            index = nullptr;
             len = (len + MSM_CH - 1) / MSM_CH;
             items_bound = out_bound;
         }
-        Point<C> *buckets = (Point<C> *)cv.take(sizeof(Point<C>) * (size_t)K);
+        char *buckets = (char *)cv.take(PB * (size_t)K);
         if (!dry) {
             const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_points, sorted, pin, seg,
-                               (const uint32_t *)nullptr, K, K, buckets, from_index ? 1 : 0);
-            c.prof_end(from_index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
+            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                               (const uint32_t *)nullptr, K, K, (void *)buckets);
+            c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
         }
-        Point<C> *A_unused;
+        char *A_unused;
         return reduce(buckets, 1u << cbits, W, cv, S_out, &A_unused);
     }
 
@@ -251,7 +263,7 @@ struct MsmRunner {
             }
             // size the workspace for the worst case (one bucket holding every point)
             Carver dry{nullptr, 0};
-            Point<C> *S_d = nullptr;
+            char *S_d = nullptr;
             int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, (uint32_t)std::min<size_t>(n, 0xffffffffu));
             if (rc) return rc;
             if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
@@ -259,14 +271,14 @@ struct MsmRunner {
             rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, 0);
             if (rc) return rc;
             LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
-            std::vector<Point<C>> S(W);
-            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, sizeof(Point<C>) * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            std::vector<char> S(PB * W);
+            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, PB * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             // fold windows most-significant first: acc <- 2^c * acc + S_w  (pippenger.rs:101)
-            result = S[W - 1];
+            result = pt_load<C>(S.data() + PB * (W - 1));
             for (uint32_t w = W - 1; w-- > 0;) {
                 for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
-                result = pt_add<C>(result, S[w]);
+                result = pt_add<C>(result, pt_load<C>(S.data() + PB * w));
             }
         }
         result = pt_to_affine<C>(result);
