@@ -8,7 +8,7 @@
 
 namespace lw {
 
-constexpr uint32_t MSM_CH = 64;        // points per accumulate work-item
+constexpr uint32_t MSM_CH = 32;        // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
 constexpr uint32_t MSM_G_LOG = 4;      // buckets per running-sum group (2^4): short dependent chains, many groups
 constexpr int MSM_THREADS = 128;
 
@@ -48,8 +48,11 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
             uint32_t mid = (lo + hi) >> 1;
             if (out_off[mid] <= t) lo = mid; else hi = mid;
         }
-        b = seg_off[lo] + (t - out_off[lo]) * MSM_CH;
-        e = min(seg_off[lo + 1], b + MSM_CH);
+        // the key's items are cut into np = ceil(len / CH) pieces of equal length (+-1), so the lanes of a wave run
+        // the same number of additions instead of full pieces next to a short remainder
+        const uint32_t s0 = seg_off[lo], len = seg_off[lo + 1] - s0, np = out_off[lo + 1] - out_off[lo], j = t - out_off[lo];
+        b = s0 + (uint32_t)(((uint64_t)len * j) / np);
+        e = s0 + (uint32_t)(((uint64_t)len * (j + 1)) / np);
     } else {
         b = seg_off[t];
         e = seg_off[t + 1];
