@@ -44,6 +44,7 @@ struct CosetCache {
     uint32_t words[8] = {0};
     int field = -1;
     bool inverse = false;
+    bool fold_ninv = false;
     bool valid = false;
 };
 

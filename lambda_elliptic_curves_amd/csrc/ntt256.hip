@@ -20,7 +20,8 @@ static Fe<F> host_root_of_unity(uint32_t order, bool inverse) {
 
 // lo[i] = base^i (i < 2^hbits), hi[i] = base^(i * 2^hbits) (i < hi_count); internal 32-byte layout
 template <class F>
-static int upload_power_tables(const Fe<F> &base, uint32_t hbits, uint64_t hi_count, DeviceBuf &lo, DeviceBuf &hi) {
+static int upload_power_tables(const Fe<F> &base, uint32_t hbits, uint64_t hi_count, DeviceBuf &lo, DeviceBuf &hi,
+                               const Fe<F> *hi_scale = nullptr) {
     const uint64_t lo_count = 1ull << hbits;
     std::vector<uint32_t> hl(lo_count * 8), hh(hi_count * 8);
     Fe<F> acc = Fe<F>::one();
@@ -29,7 +30,7 @@ static int upload_power_tables(const Fe<F> &base, uint32_t hbits, uint64_t hi_co
         acc = fe_mul<F>(acc, base);
     }
     Fe<F> step = acc;   // base^(2^hbits)
-    acc = Fe<F>::one();
+    acc = hi_scale ? *hi_scale : Fe<F>::one();
     for (uint64_t i = 0; i < hi_count; i++) {
         for (int k = 0; k < 8; k++) hh[i * 8 + k] = acc.v[k];
         acc = fe_mul<F>(acc, step);
@@ -130,9 +131,10 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
 // cached two-level power tables of `base` (optionally inverted): base^e = lo[e & mask] * hi[e >> hbits]
 template <class F>
 static int power_tables(Context &c, int field, int slot, const uint32_t *base_words, bool invert, uint32_t hbits,
-                        uint32_t hi_bits, hipStream_t stream, const uint4 **lo, const uint4 **hi) {
+                        uint32_t hi_bits, hipStream_t stream, const uint4 **lo, const uint4 **hi, bool fold_ninv = false) {
     CosetCache &cc = c.coset[slot];
-    bool hit = cc.valid && cc.field == field && cc.hbits == hbits && cc.hi_bits == hi_bits && cc.inverse == invert;
+    bool hit = cc.valid && cc.field == field && cc.hbits == hbits && cc.hi_bits == hi_bits && cc.inverse == invert &&
+               cc.fold_ninv == fold_ninv;
     for (int i = 0; i < 8 && hit; i++) hit = cc.words[i] == base_words[i];
     if (!hit) {
         Fe<F> b;
@@ -143,9 +145,11 @@ static int power_tables(Context &c, int field, int slot, const uint32_t *base_wo
         }
         if (invert) b = fe_inv<F>(b);
         LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);   // previous users of the cached tables
-        int rc = upload_power_tables<F>(b, hbits, 1ull << hi_bits, cc.lo, cc.hi);
+        Fe<F> ninv = fe_inv<F>(fe_from_u64<F>(1ull << (hbits + hi_bits)));   // N^-1 folded into the high table
+        int rc = upload_power_tables<F>(b, hbits, 1ull << hi_bits, cc.lo, cc.hi, fold_ninv ? &ninv : nullptr);
         if (rc) return rc;
         cc.valid = true;
+        cc.fold_ninv = fold_ninv;
         cc.field = field;
         cc.hbits = hbits;
         cc.hi_bits = hi_bits;
@@ -154,25 +158,6 @@ static int power_tables(Context &c, int field, int slot, const uint32_t *base_wo
     }
     *lo = (const uint4 *)cc.lo.p;
     *hi = (const uint4 *)cc.hi.p;
-    return LW_OK;
-}
-
-template <class F>
-static int scale_by_powers(Context &c, int field, const uint32_t *base_words, bool invert, const void *d_in,
-                           void *d_out, uint32_t log2n, uint32_t batch, uint64_t in_stride, uint64_t out_stride,
-                           hipStream_t stream) {
-    const uint32_t hbits = (log2n + 1) / 2;
-    const uint4 *lo, *hi;
-    int rc = power_tables<F>(c, field, invert ? 1 : 0, base_words, invert, hbits, log2n - hbits, stream, &lo, &hi);
-    if (rc) return rc;
-    const uint64_t n = 1ull << log2n;
-    const uint32_t threads = 256;
-    dim3 grid((uint32_t)((n + threads - 1) / threads), batch);
-    hipEvent_t pe = c.prof_begin(stream);
-    hipLaunchKernelGGL((scale_powers_kernel<F>), grid, dim3(threads), 0, stream, (const uint4 *)d_in, (uint4 *)d_out, lo, hi,
-                       hbits, n, in_stride, out_stride);
-    c.prof_end("scale_powers_kernel", pe, stream);
-    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     return LW_OK;
 }
 
@@ -192,17 +177,18 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
     const uint4 *tw = (const uint4 *)c.tw[field][dir].buf.p;
 
     NttPlan pl = plan_passes(log2n, g_ntt_max_r);
-    const bool need_scratch = pl.npass > 1 || d_in == d_out || (coset_words && dir == LW_DIR_FORWARD);
+    const bool need_scratch = pl.npass > 1 || d_in == d_out;
     if (need_scratch && c.scratch.ensure((size_t)n * batch * 32)) return LW_ERR_ALLOC;
     c.timings.scratch_bytes = c.scratch.bytes;
 
     const void *src = d_in;
     uint64_t src_stride = stride;
-    if (coset_words && dir == LW_DIR_FORWARD) {   // c_j * h^j before the transform (evaluate_offset_fft)
-        rc = scale_by_powers<F>(c, field, coset_words, false, d_in, c.scratch.p, log2n, batch, stride, n, stream);
+    const uint4 *cos_lo = nullptr, *cos_hi = nullptr;
+    const uint32_t cos_hbits = (log2n + 1) / 2;
+    if (coset_words) {   // coset scaling is fused into the first pass's load / the last pass's store
+        const bool inv = dir == LW_DIR_INVERSE;
+        rc = power_tables<F>(c, field, inv ? 1 : 0, coset_words, inv, cos_hbits, log2n - cos_hbits, stream, &cos_lo, &cos_hi, inv);
         if (rc) return rc;
-        src = c.scratch.p;
-        src_stride = n;
     }
 
     if (pl.npass == 1 && src == d_out) {
@@ -219,6 +205,11 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         p.tw = tw;
         p.dbg = g_ntt_dbg;
         p.lazy_in = (F::LAZY && i > 0) ? 1 : 0;
+        p.cos_lo = cos_lo;
+        p.cos_hi = cos_hi;
+        p.cos_hbits = cos_hbits;
+        p.cos_in = (coset_words && dir == LW_DIR_FORWARD && i == 0) ? 1 : 0;
+        p.cos_out = (coset_words && dir == LW_DIR_INVERSE && last) ? 1 : 0;
         p.L = log2n;
         p.s0 = pl.s0[i];
         p.r = pl.r[i];
@@ -254,10 +245,6 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         src_stride = p.out_batch_stride;
     }
 
-    if (coset_words && dir == LW_DIR_INVERSE) {   // interpolate_offset_fft: scale by offset^-i afterwards
-        rc = scale_by_powers<F>(c, field, coset_words, true, d_out, d_out, log2n, batch, stride, stride, stream);
-        if (rc) return rc;
-    }
     return LW_OK;
 }
 

@@ -49,6 +49,10 @@ struct NttPassParams {
     uint32_t logC;         // log2 columns per tile
     uint32_t nsteps;
     uint32_t k[8];         // stages per register step, sum = r
+    const uint4 *cos_lo, *cos_hi;   // coset powers h^e = cos_lo[e & mask] * cos_hi[e >> cos_hbits] (internal layout), or null
+    uint32_t cos_hbits;
+    uint32_t cos_in;       // first pass: multiply element e by h^e on load (Polynomial::scale, polynomial/mod.rs:259-271)
+    uint32_t cos_out;      // last pass of an inverse transform: multiply natural output i by h^-i * N^-1 (folded into cos_hi)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
     uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
@@ -133,6 +137,11 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
             q1 = lds[1][idx];
         }
         x[j] = unpack_mem<F>(q0, q1);
+        if (step == 0 && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
+            const uint64_t e = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
+            Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, e & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, e >> p.cos_hbits));
+            x[j] = fe_mul<F>(x[j], pw);
+        }
     }
 
     // Lazy reduction (fields with 4+ spare bits, F::LAZY): values ride in [0, 17p) — a butterfly is
@@ -184,7 +193,16 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
     }
 
-    if (last_step && p.scale) {
+    if (LAST && last_step && p.cos_out) {   // interpolate_offset_fft: N^-1 and h^-i in one product
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const uint32_t m = mbase | ((uint32_t)j << sh);
+            const uint64_t i_nat = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)blockIdx.x << logC) + c;
+            Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, i_nat & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, i_nat >> p.cos_hbits));
+            if (F::LAZY) x[j] = fe_cond_sub_kp<F, 0>(fe_mul_lazy<F>(pw, x[j]));
+            else x[j] = fe_mul<F>(x[j], pw);
+        }
+    } else if (last_step && p.scale) {
         Fe<F> sc;
 #pragma unroll
         for (int i = 0; i < 8; i++) sc.v[i] = p.sc[i];
@@ -283,26 +301,6 @@ __global__ void twiddle_fill_kernel(uint4 *tw, const uint4 *lo, const uint4 *hi,
     Fe<F> a = tw_load<F>(lo, e & ((1u << hbits) - 1));
     Fe<F> b = tw_load<F>(hi, e >> hbits);
     tw_store<F>(tw, g, fe_mul<F>(a, b));
-}
-
-// x[i] *= h^i  (Polynomial::scale, math/src/polynomial/mod.rs:259-271), h^i = lo[i & mask] * hi[i >> hbits];
-// optional extra constant factor (used to fold N^-1 when it was not fused elsewhere)
-template <class F>
-__global__ void scale_powers_kernel(const uint4 *in, uint4 *out, const uint4 *lo, const uint4 *hi, uint32_t hbits,
-                                    uint64_t n, uint64_t in_batch_stride, uint64_t out_batch_stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint4 *gin = in + 2 * (uint64_t)blockIdx.y * in_batch_stride;
-    uint4 *gout = out + 2 * (uint64_t)blockIdx.y * out_batch_stride;
-    Fe<F> a = tw_load<F>(lo, i & ((1ull << hbits) - 1));
-    Fe<F> b = tw_load<F>(hi, i >> hbits);
-    Fe<F> pw = fe_mul<F>(a, b);
-    Fe<F> x = unpack_mem<F>(gin[2 * i], gin[2 * i + 1]);
-    x = fe_mul<F>(x, pw);
-    uint4 q0, q1;
-    pack_mem<F>(x, q0, q1);
-    gout[2 * i] = q0;
-    gout[2 * i + 1] = q1;
 }
 
 }  // namespace lw
