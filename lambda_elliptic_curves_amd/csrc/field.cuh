@@ -637,10 +637,13 @@ struct BabyBear {
 };
 
 LW_HD uint32_t bb_reduce(uint64_t x) {   // x * 2^-32 mod p, x < p * 2^32
-    uint32_t t = (uint32_t)x * BabyBear::MU;
-    uint64_t u = (uint64_t)t * BabyBear::P;
-    uint32_t hi = (uint32_t)((x - u) >> 32);
-    return (x < u) ? hi + BabyBear::P : hi;
+    // t = lo(x) * p^-1; u = t * p has lo(u) == lo(x), so (x - u) / 2^32 = hi(x) - hi(u), plus p on borrow
+    // (same value as the reference's montgomery_reduction, u32_montgomery_backend_prime_field.rs:278-292)
+    const uint32_t t = (uint32_t)x * BabyBear::MU;
+    const uint32_t u_hi = (uint32_t)(((uint64_t)t * BabyBear::P) >> 32);
+    const uint32_t x_hi = (uint32_t)(x >> 32);
+    const uint32_t d = x_hi - u_hi;
+    return x_hi < u_hi ? d + BabyBear::P : d;
 }
 LW_HD uint32_t bb_mul(uint32_t a, uint32_t b) { return bb_reduce((uint64_t)a * b); }
 LW_HD uint32_t bb_add(uint32_t a, uint32_t b) {

@@ -7,6 +7,7 @@
 // Same NR-DIT dataflow and pass structure as ntt_kernels.cuh (math/src/fft/cpu/fft.rs:20-55 +
 // bit_reversing.rs:2-18); registers and LDS hold u32 values in the R = 2^32 domain, the u64 shapes are
 // converted on load/store (field.cuh bb_from_r64 / bb_to_r64), which returns the same canonical residues.
+#include <stdlib.h>
 #include <vector>
 #include "context.h"
 #include "field.cuh"
@@ -291,6 +292,8 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         const uint32_t blocks = 1u << (log2n + lgV - p.r - p.logC);
         dim3 grid(blocks, batch);
         hipEvent_t pe = c.prof_begin(stream);
+        // (a 4-columns-per-lane variant of this kernel measured no faster — the pass is bound by butterfly issue and
+        // LDS exchange, not by the width of its memory instructions)
         if (last) hipLaunchKernelGGL((bb_pass_kernel<true, W64>), grid, dim3(BB_THREADS), 0, stream, p);
         else hipLaunchKernelGGL((bb_pass_kernel<false, W64>), grid, dim3(BB_THREADS), 0, stream, p);
         c.prof_end(last ? "bb_pass_kernel<last>" : "bb_pass_kernel", pe, stream);
