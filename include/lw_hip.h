@@ -126,6 +126,14 @@ int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const 
                       uint32_t log2n, uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null,
                       void *hip_stream);
 
+/* Low-degree extension on device buffers: the forward transform of 2^log2_coeffs coefficients (batch blocks, dense)
+ * zero-padded to 2^log2n, i.e. Polynomial::evaluate_fft / evaluate_offset_fft with blowup_factor / domain_size
+ * (math/src/fft/polynomial.rs:30-38) as the STARK prover calls it (provers/stark/src/prover.rs:150-167), without
+ * materialising the padding: the log2n - log2_coeffs stages that would only replicate the block are skipped.
+ * 256-bit fields only; d_out must not alias d_coeffs. */
+int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_coeffs, uint32_t log2_coeffs, void *d_out,
+                          uint32_t log2n, uint32_t batch, const void *coset_offset_or_null, void *hip_stream);
+
 /* RootsConfig (math/src/field/traits.rs): 0 Natural, 1 NaturalInversed, 2 BitReverse, 3 BitReverseInversed.
  * Writes 2^order / 2 domain-field elements (host buffer, the layout's base word type).  order > 63 ->
  * LW_ERR_ORDER_TOO_LARGE; order > TWO_ADICITY -> LW_ERR_ROOT_OF_UNITY; order 0 -> nothing written. */

@@ -21,7 +21,7 @@ EXPORTS = [
     "lw_hip_init", "lw_hip_shutdown", "lw_hip_device_count", "lw_hip_last_error", "lw_hip_get_timings",
     "lw_hip_profile_begin", "lw_hip_profile_end",
     "lw_hip_field_elem_bytes", "lw_hip_curve_point_bytes", "lw_hip_ntt", "lw_hip_ntt_device", "lw_hip_ntt_cross_device",
-    "lw_hip_gen_twiddles", "lw_hip_bitrev_permutation",
+    "lw_hip_gen_twiddles", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
 ]
 
@@ -79,6 +79,8 @@ def lib():
     L.lw_hip_ntt_device.restype = i
     L.lw_hip_ntt_cross_device.argtypes = [i, i, i, vp, vp, u32, u32, C.c_uint64, C.c_uint64, C.c_uint64, u32, C.c_uint64, vp]
     L.lw_hip_ntt_cross_device.restype = i
+    L.lw_hip_ntt_lde_device.argtypes = [i, i, vp, u32, vp, u32, u32, vp, vp]
+    L.lw_hip_ntt_lde_device.restype = i
     L.lw_hip_gen_twiddles.argtypes = [i, i, C.c_uint64, i, vp]
     L.lw_hip_gen_twiddles.restype = i
     L.lw_hip_bitrev_permutation.argtypes = [i, i, vp, vp, sz]

@@ -111,7 +111,7 @@ int ensure_init() {
 
 // defined in ntt256.hip / ntt_bb.hip / msm.hip
 int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
-                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream);
+                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream, uint32_t in_log2);
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
                   uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
@@ -149,8 +149,10 @@ static void words_from_ref(const void *ref, uint32_t *w) {
     for (int k = 0; k < 8; k++) w[k] = m[2 * (3 - k / 2) + (k & 1)];
 }
 
+// in_log2 < log2n (256-bit fields, forward only): low-degree extension of 2^in_log2 coefficients, see ntt256.hip
 static int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
-                             uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream) {
+                             uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream,
+                             uint32_t in_log2 = 0xffffffffu) {
     int rc = check_field_layout(field, layout);
     if (rc) return rc;
     if (dir != LW_DIR_FORWARD && dir != LW_DIR_INVERSE) {
@@ -178,10 +180,29 @@ static int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, l
         set_error("null buffer");
         return LW_ERR_BAD_ARG;
     }
+    if (in_log2 > log2n) in_log2 = log2n;
+    if (in_log2 < log2n && (field == LW_FIELD_BABYBEAR || dir != LW_DIR_FORWARD || d_in == d_out)) {
+        set_error("low-degree extension needs a 256-bit field, the forward direction and distinct buffers");
+        return LW_ERR_BAD_ARG;
+    }
+    // grid.y carries the batch: split very wide batches
+    const uint32_t max_batch = 32768;
+    if (batch > max_batch) {
+        const size_t eb = lw_hip_field_elem_bytes(field, layout);
+        const size_t s_out = stride ? stride : ((size_t)1 << log2n);
+        const size_t s_in = in_log2 < log2n ? ((size_t)1 << in_log2) : s_out;
+        for (uint32_t b0 = 0; b0 < batch; b0 += max_batch) {
+            const uint32_t nb = batch - b0 < max_batch ? batch - b0 : max_batch;
+            int rc2 = ntt_device_locked(c, field, layout, dir, (const char *)d_in + (size_t)b0 * s_in * eb,
+                                        (char *)d_out + (size_t)b0 * s_out * eb, log2n, nb, stride, coset, stream, in_log2);
+            if (rc2) return rc2;
+        }
+        return LW_OK;
+    }
     if (field == LW_FIELD_BABYBEAR) return ntt_bb_device(c, layout, dir, d_in, d_out, log2n, batch, stride, coset, stream);
     uint32_t cw[8];
     if (coset) words_from_ref(coset, cw);
-    return ntt256_device(c, (int)field, dir, d_in, d_out, log2n, batch, stride, coset ? cw : nullptr, stream);
+    return ntt256_device(c, (int)field, dir, d_in, d_out, log2n, batch, stride, coset ? cw : nullptr, stream, in_log2);
 }
 
 }  // namespace lw
@@ -370,6 +391,21 @@ int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, 
                             batch, batch_stride_elems, (hipStream_t)hip_stream);
 }
 
+int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_coeffs, uint32_t log2_coeffs, void *d_out,
+                          uint32_t log2n, uint32_t batch, const void *coset_offset_or_null, void *hip_stream) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (log2_coeffs > log2n) { set_error("2^%u coefficients do not fit a 2^%u domain", log2_coeffs, log2n); return LW_ERR_BAD_ARG; }
+    auto t0 = std::chrono::steady_clock::now();
+    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, d_coeffs, d_out, log2n, batch, 0, coset_offset_or_null,
+                           (hipStream_t)hip_stream, log2_coeffs);
+    c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.ntt_calls++;
+    return rc;
+}
+
 int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t log2n, uint32_t batch,
                size_t batch_stride_elems, const void *coset_offset_or_null) {
     Context &c = ctx();
@@ -444,11 +480,19 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
     rc = ensure_init();
     if (rc) return rc;
     auto t0 = std::chrono::steady_clock::now();
-    if (c.host_io_a.ensure(len * eb) || c.host_io_b.ensure(len * eb)) return LW_ERR_ALLOC;
-    // zero padding happens after scaling in the reference, so padded slots stay zero either way
-    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, len * eb, 0), LW_ERR_LAUNCH);
+    // Zero padding happens after scaling in the reference, so padded slots stay zero either way.  For the 256-bit
+    // fields only the power-of-two block that holds the coefficients is uploaded; the transform extends it (LDE path).
+    size_t block = 1;
+    while (block < clen) block <<= 1;
+    uint32_t in_log2 = 0;
+    while (((size_t)1 << in_log2) < block) in_log2++;
+    const bool lde = field != LW_FIELD_BABYBEAR && in_log2 >= 1 && in_log2 < log2n;
+    const size_t up = lde ? block : len;
+    if (c.host_io_a.ensure(up * eb) || c.host_io_b.ensure(len * eb)) return LW_ERR_ALLOC;
+    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, up * eb, 0), LW_ERR_LAUNCH);
     LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, coeffs, clen * eb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
-    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, 0);
+    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, 0,
+                           lde ? in_log2 : log2n);
     if (rc) return rc;
     LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, len * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -86,12 +86,14 @@ uint32_t ntt_get_debug() { return g_ntt_dbg; }
 static int cfg_tile_log() { return g_ntt_cfg == 1 ? NttCfgB::TILE_LOG : NttCfgA::TILE_LOG; }
 static int cfg_kmax() { return g_ntt_cfg == 2 ? NttCfgC::KMAX : NttCfgA::KMAX; }
 
-static NttPlan plan_passes(uint32_t L, uint32_t max_r) {
+// stages [skip, L): the first `skip` stages of a zero-padded input only replicate it (see ntt256_run)
+static NttPlan plan_passes(uint32_t L, uint32_t max_r, uint32_t skip = 0) {
     const uint32_t NTT_TILE_LOG = (uint32_t)cfg_tile_log();
     NttPlan pl{};
-    pl.npass = (int)((L + max_r - 1) / max_r);
+    const uint32_t Ls = L - skip;
+    pl.npass = (int)((Ls + max_r - 1) / max_r);
     if (pl.npass < 1) pl.npass = 1;
-    uint32_t base = L / pl.npass, extra = L % pl.npass, s = 0;
+    uint32_t base = Ls / pl.npass, extra = Ls % pl.npass, s = skip;
     for (int i = 0; i < pl.npass; i++) {
         uint32_t r = base + ((uint32_t)i < extra ? 1 : 0);
         pl.s0[i] = s;
@@ -163,9 +165,18 @@ static int power_tables(Context &c, int field, int slot, const uint32_t *base_wo
 
 template <class F>
 static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
-                      uint32_t batch, uint64_t stride, const uint32_t *coset_words, hipStream_t stream) {
+                      uint32_t batch, uint64_t stride, const uint32_t *coset_words, hipStream_t stream, uint32_t in_log2) {
     const uint64_t n = 1ull << log2n;
     if (stride == 0) stride = n;
+    // Low-degree extension (evaluate_fft with blowup / domain_size, math/src/fft/polynomial.rs:30-38): the input has
+    // 2^in_log2 coefficients and the rest of the 2^log2n vector is zero padding.  In the NR-DIT dataflow the first
+    // `skip` = log2n - in_log2 stages pair every element with a zero, (a + w*0, a - w*0) = (a, a): they only replicate
+    // the coefficient block.  So those stages are skipped and the first pass reads element g from in[g mod 2^in_log2]:
+    // skip/log2n of the products and all reads of the padding are saved (blow-up 8 at 2^24: 12.5 %).
+    uint32_t skip = 0;
+    if (dir == LW_DIR_FORWARD && in_log2 >= 1 && in_log2 < log2n) skip = log2n - in_log2;
+    const uint64_t in_mask = skip ? ((1ull << in_log2) - 1) : ~0ull;
+    const uint64_t in_stride_default = skip ? (1ull << in_log2) : n;
     if (log2n == 0) {   // N = 1: the transform (and N^-1 = 1, h^0 = 1) is the identity
         if (d_in != d_out)
             LW_HIP_CHECK(hipMemcpy2DAsync(d_out, stride * 32, d_in, stride * 32, 32, batch, hipMemcpyDeviceToDevice, stream),
@@ -176,13 +187,13 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
     if (rc) return rc;
     const uint4 *tw = (const uint4 *)c.tw[field][dir].buf.p;
 
-    NttPlan pl = plan_passes(log2n, g_ntt_max_r);
+    NttPlan pl = plan_passes(log2n, g_ntt_max_r, skip);
     const bool need_scratch = pl.npass > 1 || d_in == d_out;
     if (need_scratch && c.scratch.ensure((size_t)n * batch * 32)) return LW_ERR_ALLOC;
     c.timings.scratch_bytes = c.scratch.bytes;
 
     const void *src = d_in;
-    uint64_t src_stride = stride;
+    uint64_t src_stride = skip ? in_stride_default : stride;
     const uint4 *cos_lo = nullptr, *cos_hi = nullptr;
     const uint32_t cos_hbits = (log2n + 1) / 2;
     if (coset_words) {   // coset scaling is fused into the first pass's load / the last pass's store
@@ -191,7 +202,7 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         if (rc) return rc;
     }
 
-    if (pl.npass == 1 && src == d_out) {
+    if (pl.npass == 1 && src == d_out && !skip) {
         // single pass on aliased buffers: the last pass permutes across tiles, so stage the input first
         LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, n * 32, d_in, stride * 32, n * 32, batch, hipMemcpyDeviceToDevice, stream),
                      LW_ERR_LAUNCH);
@@ -205,6 +216,7 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         p.tw = tw;
         p.dbg = g_ntt_dbg;
         p.lazy_in = (F::LAZY && i > 0) ? 1 : 0;
+        p.in_mask = i == 0 ? in_mask : ~0ull;
         p.cos_lo = cos_lo;
         p.cos_hi = cos_hi;
         p.cos_hbits = cos_hbits;
@@ -280,11 +292,12 @@ const uint4 *ntt256_twiddle_table(Context &c, int field, lw_dir_t dir, uint32_t 
     return (const uint4 *)c.tw[field][dir].buf.p;
 }
 
+// in_log2 < log2n: d_in holds `batch` blocks of 2^in_log2 coefficients (dense), d_out 2^log2n evaluations each
 int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
-                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream) {
+                  uint64_t stride, const uint32_t *coset_words, hipStream_t stream, uint32_t in_log2) {
     if (field == LW_FIELD_STARK252)
-        return ntt256_run<Stark252>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream);
-    return ntt256_run<Fr381>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream);
+        return ntt256_run<Stark252>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream, in_log2);
+    return ntt256_run<Fr381>(c, field, dir, d_in, d_out, log2n, batch, stride, coset_words, stream, in_log2);
 }
 
 }  // namespace lw

@@ -53,6 +53,7 @@ struct NttPassParams {
     uint32_t cos_hbits;
     uint32_t cos_in;       // first pass: multiply element e by h^e on load (Polynomial::scale, polynomial/mod.rs:259-271)
     uint32_t cos_out;      // last pass of an inverse transform: multiply natural output i by h^-i * N^-1 (folded into cos_hi)
+    uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
     uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
@@ -128,8 +129,8 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
                 q0 = make_uint4(m, c, 1, 2);
                 q1 = make_uint4(3, 4, 5, 6);
             } else {
-                q0 = gin[2 * g];
-                q1 = gin[2 * g + 1];
+                q0 = gin[2 * (g & p.in_mask)];
+                q1 = gin[2 * (g & p.in_mask) + 1];
             }
         } else {
             uint32_t idx = (m << logC) | c;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
         x[j] = unpack_mem<F>(q0, q1);
         if (step == 0 && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
-            const uint64_t e = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
+            const uint64_t e = (LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c)) & p.in_mask;
             Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, e & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, e >> p.cos_hbits));
             x[j] = fe_mul<F>(x[j], pw);
         }

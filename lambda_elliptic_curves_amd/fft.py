@@ -125,6 +125,17 @@ def ntt(field, data, inverse=False, log2n=None, batch=1, batch_stride=0, offset=
     return out
 
 
+def lde_device(field, t_coeffs, log2_coeffs, t_out, log2n, batch=1, offset=None, stream=None):
+    """Device-resident low-degree extension: evaluate_offset_fft(poly, blowup, Some(domain), offset) for `batch`
+    blocks of 2^log2_coeffs coefficients -> 2^log2n evaluations each, without materialising the zero padding."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    off = _offset_arg(field, offset)
+    check(L.lib().lw_hip_ntt_lde_device(field.field, field.layout, C.c_void_p(t_coeffs.data_ptr()), log2_coeffs,
+                                        C.c_void_p(t_out.data_ptr()), log2n, batch, _ptr(off), C.c_void_p(stream)))
+
+
 def ntt_device(field, t_in, t_out, log2n, inverse=False, batch=1, batch_stride=0, offset=None, stream=None):
     """Device-resident transform on torch tensors (any dtype, bytes = reference layout); asynchronous on
     `stream` (default: torch's current stream)."""

@@ -163,3 +163,34 @@ def test_gen_twiddles_and_bitrev_permutation_match_oracle(name):
         assert np.array_equal(got.reshape(-1), O.bit_reverse_permute(oid, a).reshape(-1))
     with pytest.raises(errors.InputError):
         fft.bitrev_permutation(fld, util.rand_elems(name, 3, 1))
+
+
+@pytest.mark.parametrize("name", F256)
+@pytest.mark.parametrize("log_m,blow", [(1, 1), (3, 2), (6, 3), (9, 3), (12, 1), (13, 4), (16, 3), (17, 1)])
+def test_low_degree_extension_path(name, log_m, blow):
+    # evaluate_offset_fft(poly, blowup, Some(n), offset) as the STARK prover calls it (provers/stark/src/prover.rs:150-167);
+    # the device skips the stages that only replicate the zero-padded block — bytes must not change
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = _pair(name)
+    n = 1 << log_m
+    a = util.rand_elems(name, n, 600 + log_m)
+    a[-1, -1] |= np.uint64(1)
+    off = util.offset_elem(name, 3)
+    exp = O.evaluate_fft(oid, a, 1 << blow, n, off)
+    assert np.array_equal(fft.evaluate_offset_fft(fld, a, 1 << blow, n, off), exp)
+    assert np.array_equal(fft.evaluate_fft(fld, a, 1 << blow, n), O.evaluate_fft(oid, a, 1 << blow, n))
+    # fewer coefficients than the block (degree < n - 1) and the device entry point with a batch of 2
+    short = a[: max(1, n - n // 3)].copy()
+    short[-1, -1] |= np.uint64(1)
+    assert np.array_equal(fft.evaluate_offset_fft(fld, short, 1 << blow, n, off), O.evaluate_fft(oid, short, 1 << blow, n, off))
+    two = np.concatenate([a, util.rand_elems(name, n, 5)])
+    t_in = torch.from_numpy(two.view(np.int64)).cuda()
+    t_out = torch.empty((2 << (log_m + blow), 4), dtype=torch.int64, device="cuda")
+    fft.lde_device(fld, t_in, log_m, t_out, log_m + blow, batch=2, offset=off)
+    torch.cuda.synchronize()
+    got = t_out.cpu().numpy().view(np.uint64)
+    N = n << blow
+    assert np.array_equal(got[:N], exp)
+    pad = np.zeros((N, 4), np.uint64); pad[:n] = two[n:]
+    assert np.array_equal(got[N:], O.evaluate_fft(oid, pad, 1, N, off))
