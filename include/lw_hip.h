@@ -173,6 +173,13 @@ int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, cons
                void *out_point);
 int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n,
                       void *out_point_host, void *hip_stream);
+/* Same, but the scalars are FrElements of the curve's scalar field as they sit in memory (Montgomery form): the
+ * `.representative()` map every reference caller runs on the CPU first (provers/groth16/src/prover.rs:69-78,
+ * crypto/src/commitments/kzg.rs:159-163) is done on the device (SURVEY 8f "next" #2). */
+int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalars, const void *points, size_t n_points,
+                  void *out_point);
+int lw_hip_msm_fr_device(lw_curve_t curve, const uint64_t *d_fr_elements, const void *d_points, size_t n,
+                         void *out_point_host, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -115,7 +115,7 @@ int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
                   uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream);
+               hipStream_t stream, int scalars_montgomery);
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
@@ -235,6 +235,7 @@ void lw_hip_shutdown(void) {
         c.coset[i].valid = false;
     }
     c.msm_ws.release();
+    c.msm_scalars.release();
     c.host_io_a.release();
     c.host_io_b.release();
     c.initialised = false;
@@ -523,21 +524,30 @@ int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const vo
     return LW_OK;
 }
 
-int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
-                      void *hip_stream) {
+static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
+                            void *hip_stream, int mont) {
     Context &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
     int rc = ensure_init();
     if (rc) return rc;
     if (lw_hip_curve_point_bytes(curve) == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
     auto t0 = std::chrono::steady_clock::now();
-    rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream);
+    rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream, mont);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;
 }
+int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
+                      void *hip_stream) {
+    return msm_device_entry(curve, d_scalars, d_points, n, out_point_host, hip_stream, 0);
+}
+int lw_hip_msm_fr_device(lw_curve_t curve, const uint64_t *d_fr_elements, const void *d_points, size_t n, void *out_point_host,
+                         void *hip_stream) {
+    return msm_device_entry(curve, d_fr_elements, d_points, n, out_point_host, hip_stream, 1);
+}
 
-int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, const void *points, size_t n_points, void *out_point) {
+static int msm_host_entry(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, const void *points, size_t n_points,
+                          void *out_point, int mont) {
     const size_t pb = lw_hip_curve_point_bytes(curve);
     if (pb == 0 || !out_point) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
     if (n_scalars != n_points) {   // MSMError::LengthMismatch (math/src/msm/pippenger.rs:25-27)
@@ -556,10 +566,17 @@ int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, cons
         LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
         LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     }
-    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0);
+    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0, mont);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;
+}
+int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, const void *points, size_t n_points, void *out_point) {
+    return msm_host_entry(curve, scalars, n_scalars, points, n_points, out_point, 0);
+}
+int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalars, const void *points, size_t n_points,
+                  void *out_point) {
+    return msm_host_entry(curve, fr_elements, n_scalars, points, n_points, out_point, 1);
 }
 
 }  // extern "C"

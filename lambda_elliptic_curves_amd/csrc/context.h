@@ -69,6 +69,7 @@ struct Context {
     DeviceBuf small;         // staging for small power tables
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
+    DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     lw_timings_t timings = {};
 };

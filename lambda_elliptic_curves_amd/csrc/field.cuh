@@ -102,6 +102,24 @@ struct Fp254 {      // math/src/elliptic_curve/short_weierstrass/curves/bn_254/f
     }
 };
 
+struct Fr254 {      // BN254 scalar field (bn_254/default_types.rs:13-20): MSM scalar preparation only
+    static constexpr int N = 8;
+    static constexpr uint32_t INV = 0xefffffffu;
+    static constexpr bool LAZY = false;
+    LW_HD static constexpr uint32_t p(int i) {
+        constexpr uint32_t t[N] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t one(int i) {
+        constexpr uint32_t t[N] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return t[i];
+    }
+    LW_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t t[N] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return t[i];
+    }
+};
+
 // ---------------------------------------------------------------- multi-limb element
 template <class F>
 struct Fe {

@@ -32,6 +32,21 @@ __device__ __forceinline__ uint32_t scalar_digit(const uint32_t *s, uint32_t w, 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
+// ---- scalar preparation: FrElement (Montgomery form) -> canonical integer, i.e. `.representative()` --------------
+// Every caller of msm() first maps its witness / coefficients through representative() on the CPU
+// (provers/groth16/src/prover.rs:69-78, crypto/src/commitments/kzg.rs:159-163), one Montgomery product per scalar.
+template <class F>
+__global__ void msm_scalars_from_mont_kernel(const void *in, void *out, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_store<F>((char *)out + i * 32, fe_from_mont<F>(fe_load<F>((const char *)in + i * 32)));
+}
+void msm_launch_scalar_prep(int bn254, const void *in, void *out, uint64_t n, hipStream_t s) {
+    dim3 grid((uint32_t)((n + 255) / 256));
+    if (bn254) hipLaunchKernelGGL((msm_scalars_from_mont_kernel<Fr254>), grid, dim3(256), 0, s, in, out, n);
+    else hipLaunchKernelGGL((msm_scalars_from_mont_kernel<Fr381>), grid, dim3(256), 0, s, in, out, n);
+}
+
 // ---- bucket scatter: two-level counting sort of (point index) by key = (window, digit) ----------------------
 // Level A partitions the N*W items into coarse bins (window, high digit bits) with workgroup-local LDS histograms:
 // a workgroup counts its items per coarse bin, reserves one contiguous run per bin with a single global atomic,
@@ -280,7 +295,16 @@ int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const
 int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
 
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream) {
+               hipStream_t stream, int scalars_montgomery) {
+    if (scalars_montgomery && n) {
+        if (c.msm_scalars.ensure(n * 32)) return LW_ERR_ALLOC;
+        const int bn = (curve == LW_CURVE_BN254_G1 || curve == LW_CURVE_BN254_G2);
+        hipEvent_t pe = c.prof_begin(stream);
+        msm_launch_scalar_prep(bn, d_scalars, c.msm_scalars.p, n, stream);
+        c.prof_end("msm_scalars_from_mont_kernel", pe, stream);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        d_scalars = (const uint64_t *)c.msm_scalars.p;
+    }
     switch (curve) {
         case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host);
         case LW_CURVE_BN254_G1: return msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host);

@@ -22,6 +22,16 @@ BN254TwistCurve = Curve("BN254TwistCurve", L.CURVE_BN254_G2, 8)
 BLS12381TwistCurve = Curve("BLS12381TwistCurve", L.CURVE_BLS12_381_G2, 12)
 
 
+def msm_fr(curve, fr_elements, points):
+    """msm over FrElements as stored (Montgomery form): representative() + msm in one device call."""
+    s = np.ascontiguousarray(fr_elements, dtype=np.uint64).reshape(-1, 4)
+    p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, curve.point_words)
+    out = np.zeros(curve.point_words, dtype=np.uint64)
+    check(L.lib().lw_hip_msm_fr(curve.curve, s.ctypes.data_as(C.c_void_p), s.shape[0], p.ctypes.data_as(C.c_void_p),
+                                p.shape[0], out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 def msm(curve, cs, points):
     """pippenger::msm(cs, points): cs = (n,4) uint64 canonical scalars (MS limb first), points = (n, 3*coord_words)
     uint64 projective points.  Returns one projective point; only its affine image is canonical.

@@ -131,3 +131,22 @@ def test_msm_device_resident_large_linearity():
         outs.append(msm.msm_device(crv, ts, tp, n))
     lhs = O.ec_add(oid, outs[0], outs[1])
     assert aff(oid, lhs) == aff(oid, outs[2])
+
+
+@pytest.mark.parametrize("name,fr", [("bls12_381_g1", O.F_FR381), ("bn254_g1", O.F_FR254), ("bn254_g2", O.F_FR254)])
+def test_msm_over_montgomery_scalars_equals_representative_then_msm(name, fr):
+    # what groth16/kzg callers do: scalars.map(representative) then msm (provers/groth16/src/prover.rs:69-85)
+    from lambda_elliptic_curves_amd import msm
+    from oracle import bigint_def as D
+    crv, oid = util.curve_pairs()[name]
+    n = 500
+    _, points = util.msm_case(oid, n, 31)
+    r = D.P_FR381 if fr == O.F_FR381 else D.P_FR254
+    rng = np.random.default_rng(9)
+    ks = [int.from_bytes(rng.bytes(32), "big") % r for _ in range(n)]
+    ks[0], ks[1] = 0, r - 1
+    canon = O.ints_to_array(ks, 4)
+    mont = O.ints_to_array([O.to_mont(fr, k) for k in ks], 4)
+    got = msm.msm_fr(crv, mont, points)
+    assert aff(oid, got) == aff(oid, O.msm(oid, canon, points))
+    assert aff(oid, got) == aff(oid, msm.msm(crv, canon, points))
