@@ -165,6 +165,13 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
 int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const void *evals, size_t n,
                                   const void *offset_or_null, void *out_coeffs, size_t *coeff_len);
 
+/* ---- Groth16 quotient (SURVEY 8f "next" #3) ----
+ * QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) once the variable
+ * polynomials L, R, O have been accumulated: n_coeffs <= num_gates BLS12-381 FrElements each, num_gates a power of two.
+ * Writes 2*num_gates coefficients of h (and the stripped length, as Polynomial::new would leave it). */
+int lw_groth16_h_coefficients(const void *l_coeffs, const void *r_coeffs, const void *o_coeffs, size_t n_coeffs, size_t num_gates,
+                              void *out_h, size_t *coeff_len);
+
 /* ---- MSM ----
  * scalars: n x 4 u64, canonical integers, MS limb first (callers pass .representative()).
  * points: n projective points, not necessarily normalised (Z != 1 allowed), identity = (0:1:0).

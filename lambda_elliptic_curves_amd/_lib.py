@@ -23,7 +23,7 @@ EXPORTS = [
     "lw_hip_field_elem_bytes", "lw_hip_curve_point_bytes", "lw_hip_ntt", "lw_hip_ntt_device", "lw_hip_ntt_cross_device",
     "lw_hip_gen_twiddles", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
-    "lw_hip_msm_fr", "lw_hip_msm_fr_device",
+    "lw_hip_msm_fr", "lw_hip_msm_fr_device", "lw_groth16_h_coefficients",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
     L.lw_hip_msm.restype = i
     L.lw_hip_msm_device.argtypes = [i, vp, vp, sz, vp, vp]
     L.lw_hip_msm_device.restype = i
+    L.lw_groth16_h_coefficients.argtypes = [vp, vp, vp, sz, sz, vp, C.POINTER(sz)]
+    L.lw_groth16_h_coefficients.restype = i
     L.lw_hip_msm_fr.argtypes = [i, vp, sz, vp, sz, vp]
     L.lw_hip_msm_fr.restype = i
     L.lw_hip_msm_fr_device.argtypes = [i, vp, vp, sz, vp, vp]

@@ -119,6 +119,11 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
+int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                      uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream,
+                      uint32_t in_log2 = 0xffffffffu);
+int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d_o, uint32_t log2_gates, void *d_out, void *d_tmp,
+                     hipStream_t stream);
 
 int gen_twiddles_device(Context &c, lw_field_t field, lw_layout_t layout, uint32_t order, int config, void *d_out, hipStream_t stream);
 int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream);
@@ -150,9 +155,8 @@ static void words_from_ref(const void *ref, uint32_t *w) {
 }
 
 // in_log2 < log2n (256-bit fields, forward only): low-degree extension of 2^in_log2 coefficients, see ntt256.hip
-static int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
-                             uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream,
-                             uint32_t in_log2 = 0xffffffffu) {
+int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                      uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream, uint32_t in_log2) {
     int rc = check_field_layout(field, layout);
     if (rc) return rc;
     if (dir != LW_DIR_FORWARD && dir != LW_DIR_INVERSE) {
@@ -208,6 +212,8 @@ static int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, l
 }  // namespace lw
 
 using namespace lw;
+
+static bool elem_is_zero(const unsigned char *p, size_t eb);
 
 extern "C" {
 
@@ -537,6 +543,45 @@ static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const v
     c.timings.msm_calls++;
     return rc;
 }
+// QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) after the variable
+// polynomials have been accumulated: three coset LDEs, (l*r - o) / t pointwise, one coset INTT — one device pipeline.
+int lw_groth16_h_coefficients(const void *l_coeffs, const void *r_coeffs, const void *o_coeffs, size_t n_coeffs, size_t num_gates,
+                              void *out_h, size_t *coeff_len) {
+    if (!l_coeffs || !r_coeffs || !o_coeffs || !out_h) { set_error("null argument"); return LW_ERR_BAD_ARG; }
+    if (num_gates < 1 || (num_gates & (num_gates - 1))) {   // from_r1cs pads the gate count to a power of two (qap.rs:72-75)
+        set_error("Input length is %zu, which is not a power of two", num_gates);
+        return LW_ERR_INPUT_NOT_POW2;
+    }
+    if (n_coeffs > num_gates) { set_error("%zu coefficients for %zu gates", n_coeffs, num_gates); return LW_ERR_BAD_ARG; }
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < num_gates) lg++;
+    if (lg + 1 > Fr381::TWO_ADICITY) { set_error("no primitive 2^%u-th root of unity in this field", lg + 1); return LW_ERR_ROOT_OF_UNITY; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t n = 2 * num_gates;
+    const size_t blk = num_gates < 2 ? 2 : num_gates;   // coefficient block per polynomial on the device (zero padded)
+    // device staging: [l | r | o] coefficient blocks, then 3 evaluation vectors + output
+    if (c.host_io_a.ensure(3 * blk * 32) || c.host_io_b.ensure(4 * n * 32)) return LW_ERR_ALLOC;
+    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, 3 * blk * 32, 0), LW_ERR_LAUNCH);
+    const void *src[3] = {l_coeffs, r_coeffs, o_coeffs};
+    for (int k = 0; k < 3; k++)
+        if (n_coeffs)
+            LW_HIP_CHECK(hipMemcpy((char *)c.host_io_a.p + (size_t)k * blk * 32, src[k], n_coeffs * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    char *ev = (char *)c.host_io_b.p;
+    rc = groth16_h_device(c, c.host_io_a.p, (char *)c.host_io_a.p + blk * 32, (char *)c.host_io_a.p + 2 * blk * 32, lg,
+                          ev + 3 * n * 32, ev, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out_h, ev + 3 * n * 32, n * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    if (coeff_len) {
+        size_t clen = n;
+        while (clen > 0 && elem_is_zero((const unsigned char *)out_h + (clen - 1) * 32, 32)) clen--;
+        *coeff_len = clen;
+    }
+    return LW_OK;
+}
+
 int lw_hip_msm_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
                       void *hip_stream) {
     return msm_device_entry(curve, d_scalars, d_points, n, out_point_host, hip_stream, 0);
