@@ -165,6 +165,18 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
 int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const void *evals, size_t n,
                                   const void *offset_or_null, void *out_coeffs, size_t *coeff_len);
 
+/* ---- STARK commitment (SURVEY 8f "next" #1) ----
+ * The commitment interpolate_and_commit_main makes right after the LDE (provers/stark/src/prover.rs:229-244): each of
+ * the n_cols columns (2^log2n FieldElements, natural order, column-major) is bit-reverse permuted (bit_reverse != 0,
+ * :232-234), rows are formed (columns2rows) and BatchedMerkleTree<BatchKeccak256Backend> is built
+ * (crypto/src/merkle_tree/merkle.rs:31-56; field_element_vector.rs:41-58; utils.rs:44-72).  The permutation and the
+ * transposition are folded into the leaf hash, nothing is copied.  nodes: (2*2^log2n - 1) x 32 bytes, root first,
+ * leaves last — the reference's `nodes` vector.  n_cols = 1 is the FRI layer tree (Keccak256Backend). */
+int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse,
+                            uint8_t *out_root /* 32 bytes */, uint8_t *out_nodes_or_null);
+int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems,
+                                   uint32_t log2n, int bit_reverse, void *d_nodes, uint8_t *out_root_or_null, void *hip_stream);
+
 /* ---- Groth16 quotient (SURVEY 8f "next" #3) ----
  * QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) once the variable
  * polynomials L, R, O have been accumulated: n_coeffs <= num_gates BLS12-381 FrElements each, num_gates a power of two.

@@ -4,6 +4,6 @@ Hand-written HIP kernels behind a C ABI (include/lw_hip.h); this package is the 
 the reference's operator interface for that path (Polynomial::evaluate_fft / interpolate_fft and
 msm::pippenger::msm).  No CPU fallback.
 """
-from . import _lib, errors, fft, groth16, msm  # noqa: F401
+from . import _lib, errors, fft, groth16, merkle, msm  # noqa: F401
 
-__all__ = ["_lib", "errors", "fft", "groth16", "msm"]
+__all__ = ["_lib", "errors", "fft", "groth16", "merkle", "msm"]

@@ -122,6 +122,8 @@ int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t 
 int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                       uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream,
                       uint32_t in_log2 = 0xffffffffu);
+int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
+                         void *d_nodes, hipStream_t stream);
 int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d_o, uint32_t log2_gates, void *d_out, void *d_tmp,
                      hipStream_t stream);
 
@@ -543,6 +545,47 @@ static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const v
     c.timings.msm_calls++;
     return rc;
 }
+// interpolate_and_commit_main's commitment step (provers/stark/src/prover.rs:229-244) on device-resident LDE columns
+int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems, uint32_t log2n,
+                                   int bit_reverse, void *d_nodes, uint8_t *out_root, void *hip_stream) {
+    if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("Merkle commitment supports the 256-bit fields"); return LW_ERR_BAD_ARG; }
+    if (!d_columns || !d_nodes || n_cols == 0) { set_error("null buffer or no columns"); return LW_ERR_BAD_ARG; }
+    if (log2n > 31) { set_error("2^%u leaves", log2n); return LW_ERR_ALLOC; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (col_stride_elems == 0) col_stride_elems = 1ull << log2n;
+    rc = merkle_commit_device(c, d_columns, n_cols, col_stride_elems, log2n, bit_reverse, d_nodes, (hipStream_t)hip_stream);
+    if (rc) return rc;
+    if (out_root) {
+        LW_HIP_CHECK(hipMemcpyAsync(out_root, d_nodes, 32, hipMemcpyDeviceToHost, (hipStream_t)hip_stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream), LW_ERR_LAUNCH);
+    }
+    return LW_OK;
+}
+
+int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *out_root,
+                            uint8_t *out_nodes_or_null) {
+    if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("Merkle commitment supports the 256-bit fields"); return LW_ERR_BAD_ARG; }
+    if (!columns || !out_root || n_cols == 0) { set_error("null buffer or no columns"); return LW_ERR_BAD_ARG; }
+    if (log2n > 31) { set_error("2^%u leaves", log2n); return LW_ERR_ALLOC; }
+    const size_t n = (size_t)1 << log2n;
+    {
+        Context &c = ctx();
+        std::lock_guard<std::mutex> g(c.mu);
+        int rc = ensure_init();
+        if (rc) return rc;
+        if (c.host_io_a.ensure((size_t)n_cols * n * 32) || c.host_io_b.ensure((2 * n - 1) * 32)) return LW_ERR_ALLOC;
+        LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, columns, (size_t)n_cols * n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+        rc = merkle_commit_device(c, c.host_io_a.p, n_cols, n, log2n, bit_reverse, c.host_io_b.p, 0);
+        if (rc) return rc;
+        LW_HIP_CHECK(hipMemcpy(out_root, c.host_io_b.p, 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+        if (out_nodes_or_null) LW_HIP_CHECK(hipMemcpy(out_nodes_or_null, c.host_io_b.p, (2 * n - 1) * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    }
+    return LW_OK;
+}
+
 // QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) after the variable
 // polynomials have been accumulated: three coset LDEs, (l*r - o) / t pointwise, one coset INTT — one device pipeline.
 int lw_groth16_h_coefficients(const void *l_coeffs, const void *r_coeffs, const void *o_coeffs, size_t n_coeffs, size_t num_gates,

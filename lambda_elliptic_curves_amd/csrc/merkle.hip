@@ -1,0 +1,133 @@
+// Keccak-256 Merkle commitment of LDE columns on the device (SURVEY 8f "next" #1).
+//
+// What the STARK prover does right after every LDE (provers/stark/src/prover.rs:229-244): bit-reverse-permute each
+// column (:232-234), turn columns into rows (columns2rows) and build BatchedMerkleTree<BatchKeccak256Backend> over the
+// rows (crypto/src/merkle_tree/merkle.rs:31-56):
+//     leaf_i   = Keccak256( as_bytes(col_0[bitrev(i)]) || as_bytes(col_1[bitrev(i)]) || ... )      field_element_vector.rs:41-49
+//     parent   = Keccak256( left || right )                                                       field_element_vector.rs:51-58
+//     nodes    = [inner nodes, root first | leaves]                                               utils.rs:44-72
+// as_bytes is the raw Montgomery value big-endian (math/src/field/fields/montgomery_backed_prime_fields.rs:367-373).
+// Here the permutation and the transposition are folded into the leaf kernel's gather, so the LDE output never
+// leaves HBM and no permuted / row-major copy is materialised.
+// Keccak-256 comes from the `sha3` crate (0.10) in the reference; this is the published Keccak-f[1600] with rate 136
+// and the original 0x01..0x80 padding.
+#include "context.h"
+
+namespace lw {
+
+__constant__ uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+__device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25]) {
+    constexpr int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    constexpr int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+#pragma unroll 1
+    for (int round = 0; round < 24; round++) {
+        uint64_t bc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) bc[i] = a[i] ^ a[i + 5] ^ a[i + 10] ^ a[i + 15] ^ a[i + 20];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) a[j + i] ^= t;
+        }
+        uint64_t t = a[1];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            const int j = PIL[i];
+            const uint64_t b = a[j];
+            a[j] = rotl64(t, ROT[i]);
+            t = b;
+        }
+#pragma unroll
+        for (int j = 0; j < 25; j += 5) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) bc[i] = a[j + i];
+#pragma unroll
+            for (int i = 0; i < 5; i++) a[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        a[0] ^= KECCAK_RC[round];
+    }
+}
+
+// one work-item per leaf; columns[c] starts at cols + c * col_stride elements (4 u64 limbs each, reference layout)
+__global__ __launch_bounds__(256) void merkle_leaves_kernel(const uint64_t *cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n,
+                                                            int bit_reverse, uint64_t *nodes) {
+    const uint64_t n = 1ull << log2n;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t src = bit_reverse ? (log2n ? (uint64_t)(__brevll(i) >> (64 - log2n)) : 0) : i;
+    const uint32_t total = 4 * n_cols;             // 8-byte lanes of leaf data
+    const uint32_t nblocks = total / 17 + 1;       // rate = 17 lanes; the padding always adds at least one byte
+    uint64_t st[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) st[k] = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+#pragma unroll
+        for (int j = 0; j < 17; j++) {
+            const uint32_t s = 17 * b + j;
+            if (s < total) {
+                // as_bytes = big-endian limbs, most significant limb first; a Keccak lane is 8 stream bytes little-endian
+                const uint64_t limb = cols[((uint64_t)(s >> 2) * col_stride + src) * 4 + (s & 3)];
+                st[j] ^= __builtin_bswap64(limb);
+            } else if (s == total) {
+                st[j] ^= 0x01ull;                  // first padding byte
+            }
+        }
+        if (b + 1 == nblocks) st[16] ^= 0x8000000000000000ull;   // last padding byte of the rate
+        keccak_f1600(st);
+    }
+    uint64_t *out = nodes + (n - 1 + i) * 4;
+    out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+}
+
+// parents [new_begin, new_begin + count) from children starting at level_begin
+__global__ __launch_bounds__(256) void merkle_level_kernel(uint64_t *nodes, uint64_t level_begin, uint64_t new_begin, uint64_t count) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint64_t *ch = nodes + (level_begin + 2 * k) * 4;
+    uint64_t st[25];
+#pragma unroll
+    for (int j = 0; j < 8; j++) st[j] = ch[j];
+    st[8] = 0x01ull;
+#pragma unroll
+    for (int j = 9; j < 25; j++) st[j] = 0;
+    st[16] = 0x8000000000000000ull;
+    keccak_f1600(st);
+    uint64_t *out = nodes + (new_begin + k) * 4;
+    out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+}
+
+// d_nodes: (2 * 2^log2n - 1) * 32 bytes, root first
+int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
+                         void *d_nodes, hipStream_t stream) {
+    const uint64_t n = 1ull << log2n;
+    hipEvent_t pe = c.prof_begin(stream);
+    hipLaunchKernelGGL(merkle_leaves_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, (const uint64_t *)d_cols, n_cols,
+                       col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+    c.prof_end("merkle_leaves_kernel", pe, stream);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    // crypto/src/merkle_tree/utils.rs:44-72
+    uint64_t level_begin = n - 1, level_end = 2 * level_begin;
+    while (level_begin != level_end) {
+        const uint64_t new_begin = level_begin / 2;
+        const uint64_t count = level_begin - new_begin;
+        pe = c.prof_begin(stream);
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint64_t *)d_nodes,
+                           level_begin, new_begin, count);
+        c.prof_end("merkle_level_kernel", pe, stream);
+        level_end = level_begin - 1;
+        level_begin = new_begin;
+    }
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+}  // namespace lw

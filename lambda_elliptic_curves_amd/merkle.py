@@ -1,0 +1,37 @@
+"""Host-side mirror of the STARK prover's column commitment (provers/stark/src/prover.rs:229-244):
+bit-reverse-permute the LDE columns, columns2rows, BatchedMerkleTree<BatchKeccak256Backend>::build — one device pipeline."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .errors import check
+
+
+def commit_columns(field, columns, bit_reverse=True, return_nodes=False):
+    """columns: (n_cols, N, 4) uint64 natural-order LDE columns.  Returns the 32-byte root (and the reference's `nodes`
+    array, root first, when return_nodes)."""
+    cols = np.ascontiguousarray(columns, dtype=np.uint64)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    log2n = n.bit_length() - 1
+    if n == 0 or (1 << log2n) != n:
+        from .errors import InputError
+        raise InputError(f"Input length is {n}, which is not a power of two")
+    root = np.zeros(32, np.uint8)
+    nodes = np.zeros((2 * n - 1, 32), np.uint8) if return_nodes else None
+    check(L.lib().lw_stark_commit_columns(field.field, cols.ctypes.data_as(C.c_void_p), n_cols, log2n, 1 if bit_reverse else 0,
+                                          root.ctypes.data_as(C.c_void_p),
+                                          nodes.ctypes.data_as(C.c_void_p) if return_nodes else None))
+    return (root.tobytes(), nodes) if return_nodes else root.tobytes()
+
+
+def commit_columns_device(field, t_columns, n_cols, log2n, t_nodes, bit_reverse=True, stream=None):
+    """Device-resident: t_columns holds n_cols dense columns of 2^log2n elements, t_nodes (2*2^log2n - 1) * 32 bytes."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    root = np.zeros(32, np.uint8)
+    check(L.lib().lw_stark_commit_columns_device(field.field, C.c_void_p(t_columns.data_ptr()), n_cols, 0, log2n,
+                                                 1 if bit_reverse else 0, C.c_void_p(t_nodes.data_ptr()),
+                                                 root.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+    return root.tobytes()

@@ -20,6 +20,7 @@
 #include <string.h>
 #include <pthread.h>
 #include "orc_field.h"
+#include "orc_keccak.h"
 #include "lw_oracle.h"
 
 /* ------------------------------------------------------------------ fields */
@@ -721,4 +722,49 @@ int orc_gen_points(int curve, const void *gen, const u64 *s0, const u64 *delta, 
     CURVE_DISPATCH(curve, CALL_GEN)
 #undef CALL_GEN
     return ORC_ERR_BAD_ARG;
+}
+
+/* ------------------------------------------------------------------ Merkle commitment */
+int orc_keccak256_bytes(const uint8_t *data, size_t len, uint8_t *out32) {
+    orc_keccak256(data, len, out32);
+    return 0;
+}
+
+/* FieldElement::as_bytes for MontgomeryBackendPrimeField = value().to_bytes_be()
+   (math/src/field/fields/montgomery_backed_prime_fields.rs:367-373): raw Montgomery limbs, big-endian */
+static void elem_as_bytes_be(const u64 *limbs, int n, uint8_t *out) {
+    for (int i = 0; i < n; i++)
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(limbs[i] >> (56 - 8 * b));
+}
+
+/* interpolate_and_commit_main's commitment (provers/stark/src/prover.rs:229-244): every LDE column is bit-reverse
+   permuted (:232-234), columns2rows, then BatchedMerkleTree::<BatchKeccak256Backend>::build(rows)
+   (crypto/src/merkle_tree/merkle.rs:31-56; leaf hash field_element_vector.rs:41-49; inner nodes utils.rs:44-72).
+   columns: n_cols arrays of 2^log2n 4-limb elements (column-major).  nodes_out: (2*2^log2n - 1) * 32 bytes, root first. */
+int orc_merkle_commit_columns(const u64 *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out) {
+    const size_t n = (size_t)1 << log2n;
+    uint8_t *row = (uint8_t *)malloc((size_t)n_cols * 32 + 1);
+    if (!row) return ORC_ERR_ALLOC;
+    uint8_t *leaves = nodes_out + (n - 1) * 32;
+    for (size_t i = 0; i < n; i++) {
+        size_t src = bit_reverse ? ntt4_reverse_index(i, n) : i;
+        for (uint32_t c = 0; c < n_cols; c++) elem_as_bytes_be(columns + ((size_t)c * n + src) * 4, 4, row + (size_t)c * 32);
+        orc_keccak256(row, (size_t)n_cols * 32, leaves + i * 32);
+    }
+    free(row);
+    /* utils.rs:44-72: parents of level [begin, end] are written to [begin/2, begin) */
+    size_t level_begin = n - 1, level_end = 2 * level_begin;
+    while (level_begin != level_end) {
+        size_t new_begin = level_begin / 2;
+        size_t new_len = level_begin - new_begin;
+        for (size_t k = 0; k < new_len; k++) {
+            uint8_t buf[64];
+            memcpy(buf, nodes_out + (level_begin + 2 * k) * 32, 32);
+            memcpy(buf + 32, nodes_out + (level_begin + 2 * k + 1) * 32, 32);
+            orc_keccak256(buf, 64, nodes_out + (new_begin + k) * 32);
+        }
+        level_end = level_begin - 1;
+        level_begin = new_begin;
+    }
+    return 0;
 }

@@ -65,6 +65,9 @@ int orc_msm_naive(int curve, const uint64_t *cs, int k_limbs, const void *points
 size_t orc_optimum_window_size(size_t n);
 int orc_gen_points(int curve, const void *gen, const uint64_t *s0, const uint64_t *delta, int k_limbs, size_t n, void *out);
 
+int orc_keccak256_bytes(const uint8_t *data, size_t len, uint8_t *out32);
+int orc_merkle_commit_columns(const uint64_t *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out);
+
 #ifdef __cplusplus
 }
 #endif

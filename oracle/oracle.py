@@ -44,7 +44,7 @@ class OracleError(Exception):
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("lw_oracle.c", "lw_oracle.h", "orc_field.h", "orc_ntt_tmpl.h", "orc_ec_tmpl.h")):
+            for f in ("lw_oracle.c", "lw_oracle.h", "orc_field.h", "orc_ntt_tmpl.h", "orc_ec_tmpl.h", "orc_keccak.h")):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -374,3 +374,23 @@ def gen_points(curve, gen, s0, delta, n, k_limbs=4):
     _chk(lib().orc_gen_points(curve, _p(np.ascontiguousarray(gen)), _p(int_to_limbs(s0, k_limbs)),
                               _p(int_to_limbs(delta, k_limbs)), k_limbs, C.c_size_t(n), _p(out)))
     return out
+
+
+# ---------------------------------------------------------------- Keccak / Merkle commitment
+def keccak256(data: bytes) -> bytes:
+    out = np.zeros(32, np.uint8)
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    _chk(lib().orc_keccak256_bytes(_p(np.ascontiguousarray(buf)), C.c_size_t(len(data)), _p(out)))
+    return out.tobytes()
+
+
+def merkle_commit_columns(columns, bit_reverse=True):
+    """columns: (n_cols, N, 4) uint64, natural-order LDE columns -> nodes array ((2N-1), 32) uint8, root = nodes[0]
+    (BatchedMerkleTree over the rows of the bit-reverse-permuted columns, provers/stark/src/prover.rs:229-244)."""
+    cols = np.ascontiguousarray(columns, dtype=np.uint64)
+    n_cols, n = cols.shape[0], cols.shape[1]
+    log2n = n.bit_length() - 1
+    assert 1 << log2n == n
+    nodes = np.zeros((2 * n - 1, 32), np.uint8)
+    _chk(lib().orc_merkle_commit_columns(_p(cols), n_cols, log2n, 1 if bit_reverse else 0, _p(nodes)))
+    return nodes

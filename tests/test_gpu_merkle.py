@@ -1,0 +1,38 @@
+"""GPU parity for the Keccak-256 Merkle commitment of LDE columns against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 1), (1, 6), (2, 3), (4, 10), (5, 7), (17, 5), (34, 4), (3, 14)])
+def test_commit_matches_oracle(n_cols, log_n):
+    from lambda_elliptic_curves_amd import fft, merkle
+    n = 1 << log_n
+    cols = np.stack([util.rand_elems("stark252", n, 900 + 13 * c + log_n) for c in range(n_cols)])
+    exp = O.merkle_commit_columns(cols, bit_reverse=True)
+    root, nodes = merkle.commit_columns(fft.Stark252PrimeField, cols, return_nodes=True)
+    assert np.array_equal(nodes, exp)
+    assert root == exp[0].tobytes()
+    assert merkle.commit_columns(fft.Stark252PrimeField, cols, bit_reverse=False) == O.merkle_commit_columns(cols, False)[0].tobytes()
+
+
+def test_lde_then_commit_stays_on_device():
+    # the prover's round-1 shape: LDE of the trace columns on a coset, then commit (prover.rs:208-244), all device-resident
+    import torch
+    from lambda_elliptic_curves_amd import fft, merkle
+    fld, oid = util.field_pairs()["stark252"]
+    n_cols, log_m, blow = 3, 10, 2
+    n, N = 1 << log_m, 1 << (log_m + blow)
+    coeffs = np.concatenate([util.rand_elems("stark252", n, 5 + c) for c in range(n_cols)])
+    off = util.offset_elem("stark252", 3)
+    t_c = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    t_lde = torch.empty((n_cols * N, 4), dtype=torch.int64, device="cuda")
+    t_nodes = torch.empty(((2 * N - 1) * 4,), dtype=torch.int64, device="cuda")
+    fft.lde_device(fld, t_c, log_m, t_lde, log_m + blow, batch=n_cols, offset=off)
+    root = merkle.commit_columns_device(fld, t_lde, n_cols, log_m + blow, t_nodes)
+    exp_cols = np.stack([O.evaluate_fft(oid, coeffs[c * n:(c + 1) * n], 1 << blow, n, off) for c in range(n_cols)])
+    assert root == O.merkle_commit_columns(exp_cols, True)[0].tobytes()
