@@ -177,6 +177,16 @@ int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_co
 int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems,
                                    uint32_t log2n, int bit_reverse, void *d_nodes, uint8_t *out_root_or_null, void *hip_stream);
 
+/* One layer of the FRI commit phase (SURVEY 8f "next" #4), the loop body of commit_phase
+ * (provers/stark/src/fri/mod.rs:44-58): p' = 2 * fold_polynomial(p, zeta) (fri/fri_functions.rs:7-30), then
+ * new_fri_layer(p', coset_offset, domain_size) (fri/mod.rs:115-141): evaluation on the coset, bit-reverse permuted,
+ * Merkle tree over pairs of consecutive evaluations.  The caller (transcript owner) passes the already squared offset
+ * and halved domain.  out_poly: ceil(n/2) coefficients (+ stripped length); out_evaluation: domain_size elements
+ * (bit-reversed order, as FriLayer stores it); out_nodes: (domain_size - 1) x 32 bytes, root first. */
+int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, const void *zeta, const void *coset_offset,
+                       size_t domain_size, void *out_poly, size_t *out_poly_len, void *out_evaluation, uint8_t *out_root,
+                       uint8_t *out_nodes_or_null);
+
 /* ---- Groth16 quotient (SURVEY 8f "next" #3) ----
  * QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) once the variable
  * polynomials L, R, O have been accumulated: n_coeffs <= num_gates BLS12-381 FrElements each, num_gates a power of two.

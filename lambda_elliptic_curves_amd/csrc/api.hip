@@ -124,6 +124,9 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
                       uint32_t in_log2 = 0xffffffffu);
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
                          void *d_nodes, hipStream_t stream);
+int fri_layer_device(Context &c, lw_field_t field, const void *d_coeffs, uint64_t n, const uint32_t *d_zeta, const void *offset_ref,
+                     uint32_t log2_domain, void *d_poly, uint32_t log2_block, void *d_eval, void *d_eval_br, void *d_nodes,
+                     hipStream_t stream);
 int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d_o, uint32_t log2_gates, void *d_out, void *d_tmp,
                      hipStream_t stream);
 
@@ -582,6 +585,51 @@ int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_co
         if (rc) return rc;
         LW_HIP_CHECK(hipMemcpy(out_root, c.host_io_b.p, 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
         if (out_nodes_or_null) LW_HIP_CHECK(hipMemcpy(out_nodes_or_null, c.host_io_b.p, (2 * n - 1) * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    }
+    return LW_OK;
+}
+
+// One layer of the FRI commit phase (provers/stark/src/fri/mod.rs:44-58 + :115-141), host buffers
+int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, const void *zeta, const void *coset_offset, size_t domain_size,
+                       void *out_poly, size_t *out_poly_len, void *out_evaluation, uint8_t *out_root, uint8_t *out_nodes_or_null) {
+    if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("FRI layer supports the 256-bit fields"); return LW_ERR_BAD_ARG; }
+    if (!coeffs || !zeta || !coset_offset || !out_poly || !out_evaluation || !out_root || n_coeffs == 0) { set_error("null or empty argument"); return LW_ERR_BAD_ARG; }
+    if (domain_size < 2 || (domain_size & (domain_size - 1))) {
+        set_error("Input length is %zu, which is not a power of two", domain_size);
+        return LW_ERR_INPUT_NOT_POW2;
+    }
+    const size_t n_out = (n_coeffs + 1) / 2;
+    if (n_out > domain_size) { set_error("folded polynomial of %zu coefficients exceeds the domain %zu", n_out, domain_size); return LW_ERR_BAD_ARG; }
+    uint32_t lgd = 0, lgb = 1;
+    while (((size_t)1 << lgd) < domain_size) lgd++;
+    while (((size_t)1 << lgb) < n_out) lgb++;
+    if (lgb > lgd) lgb = lgd;
+    if (lgd > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", lgd); return LW_ERR_ROOT_OF_UNITY; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    const size_t blk = (size_t)1 << lgb;
+    // a: [coeffs | zeta words | folded block]   b: [eval | eval_br | nodes]
+    const size_t a_coeffs = n_coeffs * 32, a_zeta = 256, a_poly = blk * 32;
+    if (c.host_io_a.ensure(a_coeffs + a_zeta + a_poly) || c.host_io_b.ensure(2 * domain_size * 32 + (domain_size - 1) * 32)) return LW_ERR_ALLOC;
+    char *da = (char *)c.host_io_a.p, *db = (char *)c.host_io_b.p;
+    uint32_t zw[8];
+    words_from_ref(zeta, zw);
+    LW_HIP_CHECK(hipMemcpy(da, coeffs, a_coeffs, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpy(da + a_coeffs, zw, 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    char *d_poly = da + a_coeffs + a_zeta;
+    char *d_eval = db, *d_eval_br = db + domain_size * 32, *d_nodes = db + 2 * domain_size * 32;
+    rc = fri_layer_device(c, field, da, n_coeffs, (const uint32_t *)(da + a_coeffs), coset_offset, lgd, d_poly, lgb, d_eval, d_eval_br, d_nodes, 0);
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out_poly, d_poly, n_out * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpy(out_evaluation, d_eval_br, domain_size * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpy(out_root, d_nodes, 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    if (out_nodes_or_null) LW_HIP_CHECK(hipMemcpy(out_nodes_or_null, d_nodes, (domain_size - 1) * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    if (out_poly_len) {   // Polynomial::new strips trailing zeros of the folded polynomial
+        size_t clen = n_out;
+        while (clen > 0 && elem_is_zero((const unsigned char *)out_poly + (clen - 1) * 32, 32)) clen--;
+        *out_poly_len = clen;
     }
     return LW_OK;
 }

@@ -35,3 +35,22 @@ def commit_columns_device(field, t_columns, n_cols, log2n, t_nodes, bit_reverse=
                                                  1 if bit_reverse else 0, C.c_void_p(t_nodes.data_ptr()),
                                                  root.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
     return root.tobytes()
+
+
+def fri_layer(field, coeffs, zeta, coset_offset, domain_size, return_nodes=False):
+    """One layer of commit_phase (provers/stark/src/fri/mod.rs:44-58): returns (p' = 2*fold(p, zeta) coefficients,
+    bit-reversed evaluation of p' on coset_offset * <w_domain>, Merkle root [, nodes])."""
+    a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    z = np.ascontiguousarray(zeta, dtype=np.uint64).reshape(4)
+    off = np.ascontiguousarray(coset_offset, dtype=np.uint64).reshape(4)
+    n_out = (a.shape[0] + 1) // 2
+    poly = np.zeros((n_out, 4), np.uint64)
+    ev = np.zeros((domain_size, 4), np.uint64)
+    root = np.zeros(32, np.uint8)
+    nodes = np.zeros((domain_size - 1, 32), np.uint8) if return_nodes else None
+    plen = C.c_size_t(0)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None
+    check(L.lib().lw_stark_fri_layer(field.field, vp(a), a.shape[0], vp(z), vp(off), domain_size, vp(poly), C.byref(plen), vp(ev),
+                                     vp(root), vp(nodes)))
+    out = (poly[:plen.value], ev, root.tobytes())
+    return out + (nodes,) if return_nodes else out

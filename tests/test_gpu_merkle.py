@@ -36,3 +36,27 @@ def test_lde_then_commit_stays_on_device():
     root = merkle.commit_columns_device(fld, t_lde, n_cols, log_m + blow, t_nodes)
     exp_cols = np.stack([O.evaluate_fft(oid, coeffs[c * n:(c + 1) * n], 1 << blow, n, off) for c in range(n_cols)])
     assert root == O.merkle_commit_columns(exp_cols, True)[0].tobytes()
+
+
+@pytest.mark.parametrize("n_coeffs,domain", [(8, 16), (7, 8), (64, 256), (33, 64), (2, 2), (1024, 4096)])
+def test_fri_layer_matches_reference_composition(n_coeffs, domain):
+    # commit_phase loop body (provers/stark/src/fri/mod.rs:44-58) = 2*fold_polynomial + new_fri_layer (:115-141)
+    from lambda_elliptic_curves_amd import fft, merkle
+    from oracle import bigint_def as D
+    f, p = O.F_STARK252, D.P_STARK252
+    a = util.rand_elems("stark252", n_coeffs, 50 + n_coeffs)
+    a[-1, -1] |= np.uint64(1)
+    zeta_c, off_c = 0x1234567890abcdef1234567, 9      # canonical challenge and (already squared) coset offset
+    zeta, off = O.elems_to_mont(f, [zeta_c])[0], O.elems_to_mont(f, [off_c])[0]
+    c = O.elems_from_mont(f, a)
+    folded = [(2 * (c[2 * i] + (zeta_c * c[2 * i + 1] if 2 * i + 1 < n_coeffs else 0))) % p for i in range((n_coeffs + 1) // 2)]
+    while folded and folded[-1] == 0:
+        folded.pop()
+    exp_poly = O.elems_to_mont(f, folded)
+    exp_ev = O.bit_reverse_permute(f, O.evaluate_fft(f, exp_poly, 1, domain, off))
+    leaves = exp_ev.reshape(domain // 2, 2, 4)            # chunks(2) of the permuted evaluation
+    exp_nodes = O.merkle_commit_columns(np.ascontiguousarray(leaves.transpose(1, 0, 2)), bit_reverse=False)
+    poly, ev, root, nodes = merkle.fri_layer(fft.Stark252PrimeField, a, zeta, off, domain, return_nodes=True)
+    assert np.array_equal(poly, exp_poly)
+    assert np.array_equal(ev, exp_ev)
+    assert np.array_equal(nodes, exp_nodes) and root == exp_nodes[0].tobytes()
