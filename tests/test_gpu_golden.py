@@ -1,0 +1,50 @@
+"""The HIP path against the committed golden vectors (tests/golden/reference_kats.json — values the reference's own
+tests hold, plus the SURVEY anchors derived from its constants), with no oracle in between."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O      # only for integer <-> memory-layout conversion helpers
+from tests import util
+
+pytestmark = pytest.mark.gpu
+H = lambda s: int(s, 16)
+
+
+def test_msm_reproduces_reference_curve_kats(kats):
+    # 5 * point_1 (bls12_381/curve.rs:154-171) and 5 * P (bn_254/curve.rs:99-153) as one-term MSMs
+    from lambda_elliptic_curves_amd import msm
+    for name, key, pk, p5k in (("bls12_381_g1", "bls12_381_g1", "point_1", "point_1_times_5"), ("bn254_g1", "bn254_g1", "point", "point_times_5")):
+        crv, oid = util.curve_pairs()[name]
+        k = kats[key]
+        p = O.point_from_affine_ints(oid, H(k[pk][0]), H(k[pk][1]))
+        got = msm.msm(crv, O.ints_to_array([5], 4), np.stack([p]))
+        assert O.point_to_affine_ints(oid, got) == (H(k[p5k][0]), H(k[p5k][1]))
+        # 2*P + 3*P through two buckets, and the subgroup order annihilates the generator
+        got = msm.msm(crv, O.ints_to_array([2, 3], 4), np.stack([p, p]))
+        assert O.point_to_affine_ints(oid, got) == (H(k[p5k][0]), H(k[p5k][1]))
+        g = O.point_from_affine_ints(oid, H(k["generator"][0]), H(k["generator"][1]))
+        assert O.point_to_affine_ints(oid, msm.msm(crv, O.ints_to_array([H(k["subgroup_order"])], 4), np.stack([g]))) is None
+
+
+def test_ntt_reproduces_survey_anchor_vectors(kats):
+    from lambda_elliptic_curves_amd import fft
+    a = kats["survey_anchors"]
+    f = O.F_STARK252
+    ev = fft.evaluate_fft(fft.Stark252PrimeField, O.elems_to_mont(f, [1, 2, 3, 4]))
+    assert O.elems_from_mont(f, ev) == [H(x) for x in a["stark252_ntt4_1234"]]
+    # twiddle generation: w_4 and w_{2^16} (natural config, entry 1 = w)
+    assert O.elems_from_mont(f, fft.get_twiddles(fft.Stark252PrimeField, 2, fft.ROOTS_NATURAL))[1] == H(a["stark252_w4"])
+    assert O.elems_from_mont(f, fft.get_twiddles(fft.Stark252PrimeField, 16, fft.ROOTS_NATURAL)[:2])[1] == H(a["stark252_w_2_16"])
+    assert O.elems_from_mont(O.F_FR381, fft.get_twiddles(fft.FrField, 20, fft.ROOTS_NATURAL)[:2])[1] == H(a["fr381_w_2_20"])
+    assert O.elems_from_mont(O.F_BABYBEAR_U32, fft.get_twiddles(fft.Babybear31PrimeFieldU32, 20, fft.ROOTS_NATURAL)[:2])[1] == H(a["babybear_w_2_20"])
+    # interpolating the constant-one evaluations over 2^20 points gives the polynomial 1; N^-1 is the anchor value
+    one = O.elems_to_mont(f, [1])
+    n_inv = fft.interpolate_fft(fft.Stark252PrimeField, np.concatenate([one, np.zeros((3, 4), np.uint64)]))   # [1,0,0,0] -> all 1/4
+    assert O.elems_from_mont(f, n_inv) == [pow(4, -1, 0x800000000000011000000000000000000000000000000000000000000000001)] * 4
+
+
+def test_bit_reverse_table_16(kats):
+    from lambda_elliptic_curves_amd import fft
+    arr = O.elems_to_mont(O.F_BABYBEAR_U32, list(range(16)))
+    got = O.elems_from_mont(O.F_BABYBEAR_U32, fft.bitrev_permutation(fft.Babybear31PrimeFieldU32, arr))
+    assert got == kats["bit_reverse_16"]["expected"]      # bit_reversing.rs:32-35
