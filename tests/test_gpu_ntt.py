@@ -194,3 +194,27 @@ def test_low_degree_extension_path(name, log_m, blow):
     assert np.array_equal(got[:N], exp)
     pad = np.zeros((N, 4), np.uint64); pad[:n] = two[n:]
     assert np.array_equal(got[N:], O.evaluate_fft(oid, pad, 1, N, off))
+
+
+def test_full_size_2_26_round_trip_and_dc_term():
+    # BASELINE configs[1] upper end: 2^26 Stark252 elements (2 GiB per buffer), device-resident.  Size-independent
+    # properties: INTT(NTT(x)) == x, and output 0 is the sum of the inputs (raw Montgomery values add linearly).
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = _pair("stark252")
+    L = 26
+    p = 0x800000000000011000000000000000000000000000000000000000000000001
+    a = util.rand_elems("stark252", 1 << L, 2026)
+    total = 0
+    for k in range(4):                       # limb k has weight 2^(64*(3-k)); split in halves to avoid overflow
+        col = a[:, k]
+        total += (int(np.sum(col >> np.uint64(32), dtype=np.uint64)) << 32) + int(np.sum(col & np.uint64(0xffffffff), dtype=np.uint64)) << (64 * (3 - k))
+    t_in = torch.from_numpy(a.view(np.int64)).cuda()
+    t_out = torch.empty_like(t_in)
+    fft.ntt_device(fld, t_in, t_out, L)
+    torch.cuda.synchronize()
+    first = t_out[:1].cpu().numpy().view(np.uint64)
+    assert O.limbs_to_int(first[0]) == total % p
+    fft.ntt_device(fld, t_out, t_out, L, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t_out, t_in)
