@@ -14,20 +14,72 @@ def adds_ref(n, num_limbs=4):
     return n * W + 2 * W * ((1 << c) - 1)
 
 
+# BLS12-381 G1 (y^2 = x^3 + 4 over Fp): public curve constants, used only to synthesise benchmark inputs
+BLS_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+BLS_GX = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+BLS_GY = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+
+
+def synth_points_bls12381_g1(n, seed):
+    """n distinct, non-normalised (Z != 1) projective BLS12-381 G1 points in the reference memory layout
+    (3 x 6 u64 limbs, most significant first, Montgomery form R = 2^384): P_0 = [s0]G, P_i = P_{i-1} + [d]G, each
+    triple re-randomised (X,Y,Z) -> (lX, lY, lZ) as SURVEY 8(d) prescribes.  Pure Python big-int affine arithmetic
+    (one modular inverse per point), so the benchmark's inputs do not come from the oracle."""
+    import random
+    p = BLS_P
+    rnd = random.Random(seed)
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    def mul(k, P):
+        acc = None
+        while k:
+            if k & 1:
+                acc = add(acc, P)
+            P = add(P, P)
+            k >>= 1
+        return acc
+
+    g = (BLS_GX, BLS_GY)
+    cur = mul(rnd.getrandbits(200) | 1, g)
+    step = mul(rnd.getrandbits(200) | 1, g)
+    R = 1 << 384
+    out = np.empty((n, 18), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i in range(n):
+        lam = rnd.getrandbits(380) | 1
+        for k, v in enumerate((cur[0] * lam % p, cur[1] * lam % p, lam % p)):
+            m = v * R % p
+            for j in range(6):
+                out[i, 6 * k + j] = (m >> (64 * (5 - j))) & mask
+        cur = add(cur, step)
+    return out
+
+
 def run_msm_leg(args, world, rank, barrier, max_over_ranks):
     import torch
     import torch.distributed as dist
     from lambda_elliptic_curves_amd import _lib, msm
-    from oracle import oracle as O          # input generation (point set) and the cross-rank check only
-    from tests import util
 
     L = args.msm_log2n
     n = 1 << L
-    oid = O.C_BLS12_381_G1
     crv = msm.BLS12381Curve
     # points: a host-generated SRS-like run of 2^16 distinct non-normalised points, tiled to n (scalars differ per slot)
     base_n = min(n, 1 << 16)
-    _, base_pts = util.msm_case(oid, base_n, 0x5EED + rank)
+    base_pts = synth_points_bls12381_g1(base_n, 0x5EED + rank)
     rng = np.random.default_rng(42 + 1000 * rank)
     scalars = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
     # reduce mod r is not required by the API (any 256-bit integer is legal, pippenger.rs doc); keep them < 2^255
@@ -57,7 +109,11 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
     dt = max_over_ranks(dt)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the oracle's restatement of the reference's sequential msm() (pippenger.rs:18-103), one thread
+        # CPU baseline: the oracle's restatement of the reference's sequential msm() (pippenger.rs:18-103), one thread.
+        # This leg is the only place the benchmark touches oracle/.
+        from oracle import oracle as O
+        from tests import util
+        oid = O.C_BLS12_381_G1
         Lc = 18
         sc_c, pts_c = util.msm_case(oid, 1 << Lc, 0x5EED)
         tc0 = time.perf_counter()

@@ -55,7 +55,8 @@ struct NttPassParams {
     uint32_t cos_out;      // last pass of an inverse transform: multiply natural output i by h^-i * N^-1 (folded into cos_hi)
     uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
-    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
+    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores (wrong results);
+                           // 32 last pass reuses 256 twiddles (wrong results); A/B switch with correct results: 16 stage twiddles up front
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -94,9 +95,9 @@ __device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
 
 // One work-item: 2^K elements, K stages in registers.
 template <class F, int K, bool LAST, int TILE>
-__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], const uint4 (*ltw)[256], const uint4 *gin,
+__device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
-                                         uint32_t hi_uniform, uint32_t hi_low, bool last_step) {
+                                         uint32_t hi_uniform, uint32_t hi_low, bool last_step, bool stage_tw) {
     constexpr int E = 1 << K;
     const uint32_t r = p.r, logC = p.logC, L = p.L;
     const uint32_t sh = r - t0 - K;
@@ -116,6 +117,18 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     if (LAST) {
         hi_c = (bitrev_bits(c, logC) << (L - r - logC)) | hi_low;
         gbase = (uint64_t)hi_c << r;
+    }
+
+    // Non-last passes stage the tile's 2^r - 1 twiddles in LDS (stage t, group x -> slot 2^t - 1 + x holds
+    // T[(hi << t) | x], shared by every column).  Their loads are issued first and the data loads right behind
+    // them, so the workgroup pays one memory latency, not two, before its first butterfly.
+    uint4 tq0, tq1;
+    const uint32_t ti = threadIdx.x;
+    if (!LAST && stage_tw && ti + 1 < (1u << r)) {
+        const uint32_t t = 31 - __clz(ti + 1), xg = ti + 1 - (1u << t);
+        const uint64_t g = ((uint64_t)hi_uniform << t) | xg;
+        tq0 = p.tw[2 * g];
+        tq1 = p.tw[2 * g + 1];
     }
 
     Fe<F> x[E];
@@ -145,6 +158,14 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
     }
 
+    if (!LAST && stage_tw) {   // uniform across the workgroup (see the kernel)
+        if (ti + 1 < (1u << r)) {
+            ltw[0][ti] = tq0;
+            ltw[1][ti] = tq1;
+        }
+        __syncthreads();
+    }
+
     // Lazy reduction (fields with 4+ spare bits, F::LAZY): values ride in [0, 17p) — a butterfly is
     //   t = w*y in [0,2p) (no final subtraction), x' = x + t, y' = x + 2p - t, so the bound grows by 2p per stage;
     // a pass has <= 8 stages and fully reduces its input on load (< p, so < 17p at its end); the last pass canonicalises on exit.
@@ -154,30 +175,44 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         for (int j = 0; j < E; j++) x[j] = fe_reduce_full(x[j]);
     }
 
-    // stage u of this step == stage s0 + t0 + u of the transform
-    if (!(p.dbg & 1))
+    // stage u of this step == stage s0 + t0 + u of the transform.  The E-1 twiddle groups of the step are walked in
+    // order q = 2^u - 1 + jt; in non-last passes group q+1's twiddle is fetched from LDS before group q's butterflies
+    // run, so its latency hides behind a Montgomery product (the sched_barrier below pins it there).
+    auto fetch_tw = [&](int q) -> Fe<F> {
+        const int u = 31 - __builtin_clz(q + 1), jt = q + 1 - (1 << u);
+        Fe<F> tw;
+        if (LAST) {
+            const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
+            tw = tw_load<F>(p.tw, (p.dbg & 32) ? ((gt | (uint32_t)jt) & 0xff) : (gt | (uint32_t)jt));
+        } else {   // slot 2^t - 1 + x of the staged table
+            const uint32_t li = (1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt);
+            uint4 a = ltw[0][li], b = ltw[1][li];
+            tw.v[0] = a.x; tw.v[1] = a.y; tw.v[2] = a.z; tw.v[3] = a.w;
+            tw.v[4] = b.x; tw.v[5] = b.y; tw.v[6] = b.z; tw.v[7] = b.w;
+        }
+        return tw;
+    };
+    if (!(p.dbg & 1)) {
+        Fe<F> tw_next;
+        if (!LAST) tw_next = fetch_tw(0);
 #pragma unroll
-    for (int u = 0; u < K; u++) {
-        const int half = 1 << (K - 1 - u);
-        const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
-#pragma unroll
-        for (int jt = 0; jt < (1 << u); jt++) {
+        for (int q = 0; q < E - 1; q++) {
+            const int u = 31 - __builtin_clz(q + 1), jt = q + 1 - (1 << u);
+            const int half = 1 << (K - 1 - u);
             Fe<F> tw;
-            if (LAST) {
-                tw = tw_load<F>(p.tw, gt | (uint32_t)jt);
-            } else {   // this tile's 2^r - 1 twiddles were staged in LDS: stage t, group x -> slot 2^t - 1 + x
-                const uint32_t li = (1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt);
-                uint4 a = ltw[0][li], b = ltw[1][li];
-                tw.v[0] = a.x; tw.v[1] = a.y; tw.v[2] = a.z; tw.v[3] = a.w;
-                tw.v[4] = b.x; tw.v[5] = b.y; tw.v[6] = b.z; tw.v[7] = b.w;
+            if (LAST) {   // the last pass is at its VGPR budget: prefetching there spills (measured slower)
+                tw = fetch_tw(q);
+            } else {
+                tw = tw_next;
+                if (q + 1 < E - 1) tw_next = fetch_tw(q + 1);
             }
+            // T[0] = 1: the first group of every stage multiplies by one (2^-t of stage t's butterflies, i.e. a
+            // quarter of the first pass's products).  The reference multiplies anyway (fft.rs:40-43); the product
+            // by the Montgomery one is the identity on canonical residues, so skipping it changes no byte.
+            const bool unit = (jt == 0) && (hi_c == 0) && (m_high == 0);
 #pragma unroll
             for (int jl = 0; jl < half; jl++) {
                 const int j = (jt << (K - u)) | jl;
-                // T[0] = 1: the first group of every stage multiplies by one (2^-t of stage t's butterflies, i.e. a
-                // quarter of the first pass's products).  The reference multiplies anyway (fft.rs:40-43); the product
-                // by the Montgomery one is the identity on canonical residues, so skipping it changes no byte.
-                const bool unit = (jt == 0) && (gt == 0);
                 if (F::LAZY) {
                     Fe<F> wb = unit ? fe_reduce_full(x[j + half]) : fe_mul_lazy<F>(tw, x[j + half]);
                     Fe<F> a = x[j];
@@ -254,7 +289,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         hi_low = bitrev_bits(b, L - r - logC);
     }
 
-    if (!LAST) {
+    // twiddle staging happens inside the first register step when every thread runs it (the usual case);
+    // tiles with fewer items than threads (small transforms) stage up front
+    const bool stage_inside = !LAST && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS && !(p.dbg & 16);
+    if ((p.dbg & 8) && blockIdx.x >= 256 && blockIdx.x < 512) {   // diagnostics: stagger the second workgroup of each CU
+        for (int i = 0; i < 4; i++) __builtin_amdgcn_s_sleep(127);
+    }
+    if (!LAST && !stage_inside) {
         // stage t of the pass uses T[(hi << t) | x], x < 2^t, shared by every column of the tile
         for (uint32_t i = tid; i + 1 < (1u << r); i += NTT_THREADS) {
             const uint32_t t = 31 - __clz(i + 1), x = i + 1 - (1u << t);
@@ -271,9 +312,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
-            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, (const uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
         }
         t0 += k;
     }
