@@ -159,18 +159,60 @@ struct Fe {
     LW_HD bool operator!=(const Fe &b) const { return !(*this == b); }
 };
 
+// ---- N-limb carry chains ----
+// Written with __builtin_addc / __builtin_subc so that hipcc emits one v_add_co/v_addc_co (v_sub_co/v_subb_co) per
+// limb; the same sums written with 64-bit temporaries compile to a v_lshl_add_u64 plus one or two v_mov per limb,
+// which tripled the cost of every field addition.  Modulus limbs enter the chains through lw_k(): an SGPR the
+// optimiser cannot see through, otherwise zero limbs break the chain into sub + cndmask pairs.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t lw_k(uint32_t x) {
+    asm("" : "+s"(x));
+    return x;
+}
+#else
+inline uint32_t lw_k(uint32_t x) { return x; }
+#endif
+template <int N>
+LW_HD uint32_t limbs_add(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_addc(a[i], b[i], c, &c);
+    return c;
+}
+template <int N>
+LW_HD uint32_t limbs_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_subc(a[i], b[i], c, &c);
+    return c;
+}
+// limb i of K*p for K = 2^LOGK
+template <class F, int LOGK>
+LW_HD constexpr uint32_t kp_limb(int i) {
+    if (LOGK == 0) return F::p(i);
+    return (F::p(i) << LOGK) | (i > 0 ? (F::p(i - 1) >> (32 - LOGK)) : 0u);
+}
+// limbs of K*p as chain operands
+template <class F, int LOGK>
+LW_HD void limbs_kp(uint32_t (&k)[F::N]) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) k[i] = lw_k(kp_limb<F, LOGK>(i));
+}
+// limbs of p AND mask; zero limbs stay literal zeros behind lw_k
+template <class F>
+LW_HD void limbs_p_masked(uint32_t (&k)[F::N], uint32_t mask) {
+#pragma unroll
+    for (int i = 0; i < F::N; i++) k[i] = F::p(i) == 0 ? lw_k(0u) : (lw_k(F::p(i)) & mask);
+}
+
 // r = a - p if a >= p else a       (a < 2p, all moduli here have a spare top bit)
 template <class F>
 LW_HD Fe<F> reduce_once(const Fe<F> &a) {
     constexpr int N = F::N;
+    uint32_t pk[N];
+    limbs_kp<F, 0>(pk);
     Fe<F> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t t = (uint64_t)a.v[i] - F::p(i) - borrow;
-        d.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
+    const uint32_t borrow = limbs_sub<N>(d.v, a.v, pk);
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
@@ -180,15 +222,8 @@ LW_HD Fe<F> reduce_once(const Fe<F> &a) {
 // IsField::add (montgomery_backed_prime_fields.rs:121-135, spare-bit branch)
 template <class F>
 LW_HD Fe<F> fe_add(const Fe<F> &a, const Fe<F> &b) {
-    constexpr int N = F::N;
     Fe<F> s;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        s.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    limbs_add<F::N>(s.v, a.v, b.v);
     return reduce_once<F>(s);
 }
 
@@ -197,22 +232,11 @@ template <class F>
 LW_HD Fe<F> fe_sub(const Fe<F> &a, const Fe<F> &b) {
     constexpr int N = F::N;
     Fe<F> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t t = (uint64_t)a.v[i] - b.v[i] - borrow;
-        d.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    uint32_t mask = borrow ? 0xffffffffu : 0u;
-    uint64_t c = 0;
+    const uint32_t borrow = limbs_sub<N>(d.v, a.v, b.v);
+    uint32_t pm[N];
+    limbs_p_masked<F>(pm, 0u - borrow);
     Fe<F> r;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)d.v[i] + (F::p(i) & mask);
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    limbs_add<N>(r.v, d.v, pm);
     return r;
 }
 
@@ -220,17 +244,15 @@ LW_HD Fe<F> fe_sub(const Fe<F> &a, const Fe<F> &b) {
 template <class F>
 LW_HD Fe<F> fe_neg(const Fe<F> &a) {
     constexpr int N = F::N;
-    Fe<F> r;
     uint32_t nz = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) nz |= a.v[i];
-    uint64_t borrow = 0;
+    uint32_t pk[N];
+    limbs_kp<F, 0>(pk);
+    Fe<F> r;
+    limbs_sub<N>(r.v, pk, a.v);
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t t = (uint64_t)F::p(i) - a.v[i] - borrow;
-        r.v[i] = nz ? (uint32_t)t : 0u;
-        borrow = (t >> 32) & 1;
-    }
+    for (int i = 0; i < N; i++) r.v[i] = nz ? r.v[i] : 0u;
     return r;
 }
 
@@ -454,24 +476,14 @@ template <class F>
 LW_HD Fe<F> fe_sqr(const Fe<F> &a) { return fe_mul<F>(a, a); }
 
 // ---- lazy-reduction helpers (fields with F::LAZY; used by the NTT butterflies only) ----
-// limb i of K*p for K a power of two
-template <class F, int LOGK>
-LW_HD constexpr uint32_t kp_limb(int i) {
-    if (LOGK == 0) return F::p(i);
-    return (F::p(i) << LOGK) | (i > 0 ? (F::p(i - 1) >> (32 - LOGK)) : 0u);
-}
 // a - K*p if a >= K*p else a
 template <class F, int LOGK>
 LW_HD Fe<F> fe_cond_sub_kp(const Fe<F> &a) {
     constexpr int N = F::N;
+    uint32_t kp[N];
+    limbs_kp<F, LOGK>(kp);
     Fe<F> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t t = (uint64_t)a.v[i] - kp_limb<F, LOGK>(i) - borrow;
-        d.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
+    const uint32_t borrow = limbs_sub<N>(d.v, a.v, kp);
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
@@ -482,24 +494,14 @@ LW_HD Fe<F> fe_cond_sub_kp(const Fe<F> &a) {
 // one 8-limb subtraction plus a conditional add of p.
 LW_HD Fe<Stark252> fe_reduce_full(const Fe<Stark252> &x) {
     const uint32_t q = x.v[7] >> 27;
-    const uint32_t sub[8] = {q, 0, 0, 0, 0, 0, 17u * q, q << 27};
+    const uint32_t z = lw_k(0u);
+    const uint32_t sub[8] = {q, z, z, z, z, z, 17u * q, q << 27};
     Fe<Stark252> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t t = (uint64_t)x.v[i] - sub[i] - borrow;
-        d.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    const uint32_t mask = borrow ? 0xffffffffu : 0u;
+    const uint32_t borrow = limbs_sub<8>(d.v, x.v, sub);
+    uint32_t pm[8];
+    limbs_p_masked<Stark252>(pm, 0u - borrow);
     Fe<Stark252> r;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)d.v[i] + (Stark252::p(i) & mask);
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    limbs_add<8>(r.v, d.v, pm);
     return r;
 }
 template <class F>
@@ -508,37 +510,19 @@ LW_HD Fe<F> fe_reduce_full(const Fe<F> &x) { return reduce_once<F>(x); }   // no
 // plain N-limb add / (a + 2p - b); the caller guarantees the range fits N limbs
 template <class F>
 LW_HD Fe<F> fe_add_raw(const Fe<F> &a, const Fe<F> &b) {
-    constexpr int N = F::N;
     Fe<F> s;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        s.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
+    limbs_add<F::N>(s.v, a.v, b.v);
     return s;
 }
 template <class F>
 LW_HD Fe<F> fe_add2p_sub_raw(const Fe<F> &a, const Fe<F> &b) {   // a + 2p - b, b <= a + 2p
     constexpr int N = F::N;
-    Fe<F> s;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)a.v[i] + kp_limb<F, 1>(i);
-        s.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    Fe<F> d;
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t t = (uint64_t)s.v[i] - b.v[i] - borrow;
-        d.v[i] = (uint32_t)t;
-        borrow = (t >> 32) & 1;
-    }
-    return d;
+    uint32_t kp[N];
+    limbs_kp<F, 1>(kp);
+    Fe<F> d, r;
+    limbs_sub<N>(d.v, a.v, b.v);      // wraps mod 2^(32N) when b > a; adding 2p brings it back into range
+    limbs_add<N>(r.v, d.v, kp);
+    return r;
 }
 // Montgomery product without the final conditional subtraction: result in [0, 2p) whenever a < p
 // (b may be any N-limb value): (a*b + m*p) / R < a*b/R + p < 2p.

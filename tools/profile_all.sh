@@ -9,12 +9,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 B="bench.py --no-cpu-baseline --steps 5 --warmup 2"
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python3 $B > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $B > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o pmc -- python3 $B --workload ntt > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OUT/pmc_$c -o pmc -- python3 $B --workload ntt > $OUT/pmc_$c.log 2>&1
 done
 for c in VALUBusy LDSBankConflict MeanOccupancyPerCU; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/pmc_$c -o pmc -- python3 $B --msm-log2n 22 > $OUT/pmc_$c.log 2>&1 || echo "counter $c failed" >> $OUT/failed.txt
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OUT/pmc_$c -o pmc -- python3 $B --msm-log2n 22 > $OUT/pmc_$c.log 2>&1 || echo "counter $c failed" >> $OUT/failed.txt
 done
 python3 tools/parse_pmc.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE 24 $OUT/traffic_latest.json
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_VALUBusy $OUT/pmc_LDSBankConflict $OUT/pmc_MeanOccupancyPerCU > $OUT/pmc_summary.csv
