@@ -415,8 +415,12 @@ __device__ __forceinline__ void col_ab_first(uint64_t &lo, uint32_t &hi, uint64_
         mac96_first_x1(lo, hi, init, a.v[I], b.v[K - I]);
     }
 }
-template <class F, int K>
-__device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe<F> &b, uint32_t (&m)[F::N], uint32_t (&t)[F::N]) {
+// Column K of sum_{q<P} a[q]*b[q] + m*p.  P > 1 accumulates several products before the single Montgomery
+// reduction (fe_dot below): the a*b MACs of every product land in the same 96-bit column accumulator and the m*p
+// MACs are paid once, so a sum of P products costs (P+1)*N^2 MACs instead of 2*P*N^2.
+template <class F, int P, int K>
+__device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> *const (&a)[P], const Fe<F> *const (&b)[P], uint32_t (&m)[F::N],
+                                         uint32_t (&t)[F::N]) {
     constexpr int N = F::N;
     if constexpr (K == 2 * N - 1) {
         t[N - 1] = (uint32_t)init;   // no products left: the last carry is the top limb
@@ -425,10 +429,16 @@ __device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe
         uint32_t hi;
         if constexpr (K < N) {
 #if defined(LW_NO_COLUMN_CHAINS)
-            col_ab_first<F, K, 0, K + 1>(lo, hi, init, a, b);
+            col_ab_first<F, K, 0, K + 1>(lo, hi, init, *a[0], *b[0]);
+#else
+            col_ab_first_dispatch<F, K, 0, K + 1>(lo, hi, init, *a[0], *b[0]);
+#endif
+            if constexpr (P > 1) col_ab<F, K, 0, K + 1>(lo, hi, *a[1], *b[1]);
+            if constexpr (P > 2) col_ab<F, K, 0, K + 1>(lo, hi, *a[2], *b[2]);
+            if constexpr (P > 3) col_ab<F, K, 0, K + 1>(lo, hi, *a[3], *b[3]);
+#if defined(LW_NO_COLUMN_CHAINS)
             col_mp<F, K, 0, K>(lo, hi, m);
 #else
-            col_ab_first_dispatch<F, K, 0, K + 1>(lo, hi, init, a, b);
             if constexpr (K >= 1 && lw_all_literal<F, 1, K + 1>()) col_mp_dispatch<F, K, 0, K>(lo, hi, m);
             else col_mp<F, K, 0, K>(lo, hi, m);
 #endif
@@ -439,23 +449,30 @@ __device__ __forceinline__ void fips_col(uint64_t init, const Fe<F> &a, const Fe
             mac96_c1<F::p(0)>(lo, hi, mk);
         } else {
 #if defined(LW_NO_COLUMN_CHAINS)
-            col_ab_first<F, K, K - N + 1, N>(lo, hi, init, a, b);
+            col_ab_first<F, K, K - N + 1, N>(lo, hi, init, *a[0], *b[0]);
+#else
+            col_ab_first_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, init, *a[0], *b[0]);
+#endif
+            if constexpr (P > 1) col_ab<F, K, K - N + 1, N>(lo, hi, *a[1], *b[1]);
+            if constexpr (P > 2) col_ab<F, K, K - N + 1, N>(lo, hi, *a[2], *b[2]);
+            if constexpr (P > 3) col_ab<F, K, K - N + 1, N>(lo, hi, *a[3], *b[3]);
+#if defined(LW_NO_COLUMN_CHAINS)
             col_mp<F, K, K - N + 1, N>(lo, hi, m);
 #else
-            col_ab_first_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, init, a, b);
             if constexpr (lw_all_literal<F, K - N + 1, N>()) col_mp_dispatch<F, K, K - N + 1, 2 * N - 1 - K>(lo, hi, m);
             else col_mp<F, K, K - N + 1, N>(lo, hi, m);
 #endif
             t[K - N] = (uint32_t)lo;
         }
-        fips_col<F, K + 1>((lo >> 32) | ((uint64_t)hi << 32), a, b, m, t);
+        fips_col<F, P, K + 1>((lo >> 32) | ((uint64_t)hi << 32), a, b, m, t);
     }
 }
 template <class F>
 __device__ __forceinline__ Fe<F> fe_mul_gfx9(const Fe<F> &a, const Fe<F> &b) {
     constexpr int N = F::N;
     uint32_t m[N], t[N];
-    fips_col<F, 0>(0ull, a, b, m, t);
+    const Fe<F> *const pa[1] = {&a}, *const pb[1] = {&b};
+    fips_col<F, 1, 0>(0ull, pa, pb, m, t);
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
@@ -474,6 +491,36 @@ LW_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
 
 template <class F>
 LW_HD Fe<F> fe_sqr(const Fe<F> &a) { return fe_mul<F>(a, a); }
+
+// p - a without the zero check of fe_neg: in (0, p], congruent to -a.  Only ever fed to fe_dot.
+template <class F>
+LW_HD Fe<F> fe_neg_raw(const Fe<F> &a) {
+    uint32_t pk[F::N];
+    limbs_kp<F, 0>(pk);
+    Fe<F> r;
+    limbs_sub<F::N>(r.v, pk, a.v);
+    return r;
+}
+// sum_{q<P} a[q]*b[q] * R^-1 mod p, canonical, operands <= p.  One reduction for P products; the result before the
+// final subtraction is < (P*p/R + 1)*p, which must stay below 2p: P*(top limb + 1) <= 2^32 (Fp381: P <= 9, Fp254: P <= 5).
+template <class F, int P>
+LW_HD Fe<F> fe_dot(const Fe<F> *const (&a)[P], const Fe<F> *const (&b)[P]) {
+    static_assert(P >= 1 && P <= 4, "fe_dot: 1..4 products");
+    static_assert((uint64_t)P * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32), "fe_dot: sum of products would exceed 2p after reduction");
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int N = F::N;
+    uint32_t m[N], t[N];
+    fips_col<F, P, 0>(0ull, a, b, m, t);
+    Fe<F> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.v[i] = t[i];
+    return reduce_once<F>(r);
+#else
+    Fe<F> acc = fe_mul_portable<F>(reduce_once<F>(*a[0]), *b[0]);
+    for (int q = 1; q < P; q++) acc = fe_add<F>(acc, fe_mul_portable<F>(reduce_once<F>(*a[q]), *b[q]));
+    return acc;
+#endif
+}
 
 // ---- lazy-reduction helpers (fields with F::LAZY; used by the NTT butterflies only) ----
 // a - K*p if a >= K*p else a
@@ -531,7 +578,8 @@ LW_HD Fe<F> fe_mul_lazy(const Fe<F> &a, const Fe<F> &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int N = F::N;
     uint32_t m[N], t[N];
-    fips_col<F, 0>(0ull, a, b, m, t);
+    const Fe<F> *const pa[1] = {&a}, *const pb[1] = {&b};
+    fips_col<F, 1, 0>(0ull, pa, pb, m, t);
     Fe<F> r;
 #pragma unroll
     for (int i = 0; i < N; i++) r.v[i] = t[i];
