@@ -687,20 +687,23 @@ struct BabyBear {
 };
 
 LW_HD uint32_t bb_reduce(uint64_t x) {   // x * 2^-32 mod p, x < p * 2^32
-    // t = lo(x) * p^-1; u = t * p has lo(u) == lo(x), so (x - u) / 2^32 = hi(x) - hi(u), plus p on borrow
-    // (same value as the reference's montgomery_reduction, u32_montgomery_backend_prime_field.rs:278-292)
-    const uint32_t t = (uint32_t)x * BabyBear::MU;
-    const uint32_t u_hi = (uint32_t)(((uint64_t)t * BabyBear::P) >> 32);
-    const uint32_t x_hi = (uint32_t)(x >> 32);
-    const uint32_t d = x_hi - u_hi;
-    return x_hi < u_hi ? d + BabyBear::P : d;
+    // m = -lo(x) * p^-1, so x + m*p is a multiple of 2^32 and (x + m*p) / 2^32 < 2p is congruent to x * 2^-32: the same
+    // canonical residue as the reference's montgomery_reduction (u32_montgomery_backend_prime_field.rs:278-292), which
+    // subtracts with the un-negated inverse instead.  On gfx950 this is v_mul_lo + v_mad_u64_u32 + v_sub + v_min.
+    const uint32_t m = (uint32_t)x * (0u - BabyBear::MU);
+    const uint32_t r = (uint32_t)((x + (uint64_t)m * BabyBear::P) >> 32);
+    const uint32_t d = r - BabyBear::P;      // wraps above r exactly when r < p
+    return d < r ? d : r;
 }
 LW_HD uint32_t bb_mul(uint32_t a, uint32_t b) { return bb_reduce((uint64_t)a * b); }
 LW_HD uint32_t bb_add(uint32_t a, uint32_t b) {
-    uint32_t s = a + b;
-    return s >= BabyBear::P ? s - BabyBear::P : s;
+    const uint32_t s = a + b, d = s - BabyBear::P;
+    return d < s ? d : s;
 }
-LW_HD uint32_t bb_sub(uint32_t a, uint32_t b) { return a >= b ? a - b : a + BabyBear::P - b; }
+LW_HD uint32_t bb_sub(uint32_t a, uint32_t b) {
+    const uint32_t d = a - b, e = d + BabyBear::P;   // a < b: d wraps to 2^32 - (b - a) and e = p - (b - a)
+    return e < d ? e : d;
+}
 LW_HD uint32_t bb_pow(uint32_t a, uint64_t e) {
     uint32_t r = BabyBear::ONE;
     while (e) {

@@ -39,20 +39,20 @@ struct BbPassParams {
 __device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
 template <bool W64>
-__device__ __forceinline__ uint32_t bb_load_word(const void *base, uint64_t idx) {
+__device__ __forceinline__ uint32_t bb_load_word(const void *base, uint32_t idx) {
     if (W64) return bb_from_r64(reinterpret_cast<const uint64_t *>(base)[idx]);
     return reinterpret_cast<const uint32_t *>(base)[idx];
 }
 template <bool W64>
-__device__ __forceinline__ void bb_store_word(void *base, uint64_t idx, uint32_t v) {
+__device__ __forceinline__ void bb_store_word(void *base, uint32_t idx, uint32_t v) {
     if (W64) reinterpret_cast<uint64_t *>(base)[idx] = bb_to_r64(v);
     else reinterpret_cast<uint32_t *>(base)[idx] = v;
 }
 
 template <int K, bool LAST, bool W64>
-__device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const void *gin, uint32_t w, uint32_t step,
-                                        uint32_t t0, uint64_t base, uint32_t lgS, uint32_t hi_uniform, uint32_t hi_low,
-                                        bool last_step) {
+__device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const void *gin, uint32_t w,
+                                        uint32_t step, uint32_t t0, uint32_t base, uint32_t lgS, uint32_t hi_uniform,
+                                        uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
     const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
     const uint32_t logCh = logC - lgV;               // columns proper (distinct tiles in the last pass)
@@ -77,10 +77,11 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
     for (int j = 0; j < E; j++) {
         const uint32_t m = mbase | ((uint32_t)j << sh);
         if (step == 0) {
-            uint64_t g;
-            if (LAST) g = (((((uint64_t)hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
-            else g = base + ((uint64_t)m << lgS) + c;
-            x[j] = (p.dbg & 2) ? (uint32_t)g : bb_load_word<W64>(gin, g);
+            // word indices fit 32 bits: two-adicity 24 (babybear.rs:29) caps a transform at 2^26 words
+            uint32_t g;
+            if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
+            else g = base + (m << lgS) + c;
+            x[j] = (p.dbg & 2) ? g : bb_load_word<W64>(gin, g);
         } else {
             x[j] = lds[(m << logC) | c];
         }
@@ -89,10 +90,11 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
 #pragma unroll
     for (int u = 0; u < K; u++) {
         const int half = 1 << (K - 1 - u);
-        const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
+        const uint32_t gt = (hi_c << (t0 + u)) | (m_high << u);
 #pragma unroll
         for (int jt = 0; jt < (1 << u); jt++) {
-            const uint32_t tw = p.tw[gt | (uint32_t)jt];
+            // non-last passes: the tile's 2^r - 1 twiddles sit in LDS, stage t group x at slot 2^t - 1 + x
+            const uint32_t tw = LAST ? p.tw[gt | (uint32_t)jt] : ltw[(1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt)];
 #pragma unroll
             for (int jl = 0; jl < half; jl++) {
                 const int j = (jt << (K - u)) | jl;
@@ -117,6 +119,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
 template <bool LAST, bool W64>
 __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     __shared__ uint32_t lds[BB_TILE];
+    __shared__ uint32_t ltw[LAST ? 1 : 256];
     const uint32_t tid = threadIdx.x;
     const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
     const uint32_t tile_log = r + logC;
@@ -126,14 +129,19 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     const uint32_t b = blockIdx.x;
     const uint32_t Lw = L + lgV;      // index bits of the word array
 
-    uint64_t base = 0;
+    uint32_t base = 0;
     uint32_t lgS = 0, hi_uniform = 0, hi_low = 0;
     if (!LAST) {
         lgS = Lw - p.s0 - r;          // row stride in words
         const uint32_t lo_bits = lgS - logC;
         const uint32_t lo_blk = b & ((1u << lo_bits) - 1);
         hi_uniform = b >> lo_bits;
-        base = ((uint64_t)hi_uniform << (Lw - p.s0)) + ((uint64_t)lo_blk << logC);
+        base = (hi_uniform << (Lw - p.s0)) + (lo_blk << logC);
+        for (uint32_t i = tid; i + 1 < (1u << r); i += BB_THREADS) {   // r <= 8: at most 255 twiddles
+            const uint32_t t = 31 - __clz(i + 1), xg = i + 1 - (1u << t);
+            ltw[i] = p.tw[(hi_uniform << t) | xg];
+        }
+        __syncthreads();
     } else {
         hi_low = bb_bitrev(b, L - r - (logC - lgV));
     }
@@ -144,10 +152,10 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += BB_THREADS) {
-            if (k == 4) bb_item<4, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 3) bb_item<3, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) bb_item<2, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else bb_item<1, LAST, W64>(p, lds, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (k == 4) bb_item<4, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 3) bb_item<3, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) bb_item<2, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else bb_item<1, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
         }
         t0 += k;
     }
@@ -157,9 +165,9 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     for (uint32_t e = tid; e < total; e += BB_THREADS) {
         const uint32_t c = e & ((1u << logC) - 1);
         const uint32_t m = e >> logC;
-        uint64_t g;
-        if (!LAST) g = base + ((uint64_t)m << lgS) + c;
-        else g = ((((uint64_t)bb_bitrev(m, r) << (L - r)) + ((uint64_t)b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
+        uint32_t g;
+        if (!LAST) g = base + (m << lgS) + c;
+        else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
         if (!(p.dbg & 4)) bb_store_word<W64>(gout, g, lds[e]);
     }
 }
