@@ -228,8 +228,12 @@ struct MsmRunner {
                 if (total) {
                     const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
                     hipEvent_t pe = c.prof_begin(stream);
-                    hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                       (const uint32_t *)out_off, K, total, (void *)pout);
+                    if (msm_waves_per_simd() == 3)
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                           (const uint32_t *)out_off, K, total, (void *)pout);
+                    else
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                           (const uint32_t *)out_off, K, total, (void *)pout);
                     c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
                 }
             }

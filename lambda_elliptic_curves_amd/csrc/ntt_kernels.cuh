@@ -56,7 +56,7 @@ struct NttPassParams {
     uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
     uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores (wrong results);
-                           // 32 last pass reuses 256 twiddles (wrong results); A/B switch with correct results: 16 stage twiddles up front
+                           // bit3 stagger the second workgroup per CU, bit4 stage twiddles before the data loads (results stay correct)
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -176,8 +176,9 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     }
 
     // stage u of this step == stage s0 + t0 + u of the transform.  The E-1 twiddle groups of the step are walked in
-    // order q = 2^u - 1 + jt; in non-last passes group q+1's twiddle is fetched from LDS before group q's butterflies
-    // run, so its latency hides behind a Montgomery product (the sched_barrier below pins it there).
+    // order q = 2^u - 1 + jt; group q+1's twiddle is fetched (LDS, or the table in the last pass) before group q's
+    // butterflies run, so its latency hides behind a Montgomery product (the sched_barrier below pins it there).
+    // Fetching all of a step's twiddles up front measured slower (more live registers, no fewer stalls).
     auto fetch_tw = [&](int q) -> Fe<F> {
         const int u = 31 - __builtin_clz(q + 1), jt = q + 1 - (1 << u);
         Fe<F> tw;
@@ -193,19 +194,13 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         return tw;
     };
     if (!(p.dbg & 1)) {
-        Fe<F> tw_next;
-        if (!LAST) tw_next = fetch_tw(0);
+        Fe<F> tw_next = fetch_tw(0);
 #pragma unroll
         for (int q = 0; q < E - 1; q++) {
             const int u = 31 - __builtin_clz(q + 1), jt = q + 1 - (1 << u);
             const int half = 1 << (K - 1 - u);
-            Fe<F> tw;
-            if (LAST) {   // the last pass is at its VGPR budget: prefetching there spills (measured slower)
-                tw = fetch_tw(q);
-            } else {
-                tw = tw_next;
-                if (q + 1 < E - 1) tw_next = fetch_tw(q + 1);
-            }
+            const Fe<F> tw = tw_next;
+            if (q + 1 < E - 1) tw_next = fetch_tw(q + 1);
             // T[0] = 1: the first group of every stage multiplies by one (2^-t of stage t's butterflies, i.e. a
             // quarter of the first pass's products).  The reference multiplies anyway (fft.rs:40-43); the product
             // by the Montgomery one is the identity on canonical residues, so skipping it changes no byte.
