@@ -79,12 +79,11 @@ struct NttPlan {
     uint32_t s0[8], r[8], logC[8];
 };
 
-static int g_ntt_cfg = 0;          // 0 = NttCfgA, 1 = NttCfgB, 2 = NttCfgC
 static uint32_t g_ntt_dbg = 0;     // diagnostics: see NttPassParams::dbg (results are wrong when set)
 void ntt_set_debug(uint32_t d) { g_ntt_dbg = d; }
 uint32_t ntt_get_debug() { return g_ntt_dbg; }
-static int cfg_tile_log() { return g_ntt_cfg == 1 ? NttCfgB::TILE_LOG : NttCfgA::TILE_LOG; }
-static int cfg_kmax() { return g_ntt_cfg == 2 ? NttCfgC::KMAX : NttCfgA::KMAX; }
+static int cfg_tile_log() { return NttCfgA::TILE_LOG; }
+static int cfg_kmax() { return NttCfgA::KMAX; }
 
 // stages [skip, L): the first `skip` stages of a zero-padded input only replicate it (see ntt256_run)
 static NttPlan plan_passes(uint32_t L, uint32_t max_r, uint32_t skip = 0) {
@@ -120,14 +119,18 @@ static void split_steps(uint32_t r, NttPassParams &p) {
 
 static uint32_t g_ntt_max_r = 8;
 void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
-void ntt_set_config(int cfg) { g_ntt_cfg = cfg < 0 || cfg > 2 ? 0 : cfg; }
+void ntt_set_config(int) {}   // alternative geometries were measured and removed (ntt_kernels.cuh)
 
 template <class F, class CFG>
 static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassParams &p) {
-    if (last)
-        hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG>), grid, dim3(CFG::THREADS), 0, stream, p);
-    else
-        hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG>), grid, dim3(CFG::THREADS), 0, stream, p);
+    const bool extra = p.cos_in || p.cos_out || p.scale;
+    if (last) {
+        if (extra) hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG, true>), grid, dim3(CFG::THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG, false>), grid, dim3(CFG::THREADS), 0, stream, p);
+    } else {
+        if (extra) hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG, true>), grid, dim3(CFG::THREADS), 0, stream, p);
+        else hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG, false>), grid, dim3(CFG::THREADS), 0, stream, p);
+    }
 }
 
 // cached two-level power tables of `base` (optionally inverted): base^e = lo[e & mask] * hi[e >> hbits]
@@ -248,9 +251,7 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         const uint32_t blocks = 1u << (log2n - p.r - p.logC);
         dim3 grid(blocks, batch);
         hipEvent_t pe = c.prof_begin(stream);
-        if (g_ntt_cfg == 1) launch_pass<F, NttCfgB>(last, grid, stream, p);
-        else if (g_ntt_cfg == 2) launch_pass<F, NttCfgC>(last, grid, stream, p);
-        else launch_pass<F, NttCfgA>(last, grid, stream, p);
+        launch_pass<F, NttCfgA>(last, grid, stream, p);
         c.prof_end(last ? "ntt_pass_kernel<last>" : "ntt_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;

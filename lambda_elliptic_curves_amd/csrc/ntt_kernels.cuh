@@ -33,8 +33,8 @@ struct NttCfg {
     static constexpr int WAVES_PER_SIMD = (WG_PER_CU * THREADS / 256) > 8 ? 8 : (WG_PER_CU * THREADS / 256) < 1 ? 1 : (WG_PER_CU * THREADS / 256);
 };
 using NttCfgA = NttCfg<11, 512, 2>;   // 64 KiB tile, 2 workgroups/CU, 4 waves/SIMD
-using NttCfgB = NttCfg<10, 256, 2>;   // 32 KiB tile, 5 workgroups/CU (desynchronised load/compute phases)
-using NttCfgC = NttCfg<11, 256, 3>;   // 64 KiB tile, radix-8 register steps, 2 waves/SIMD
+// (measured and dropped: 32 KiB tile / 256 threads -> 128-byte runs, 5.4 G elem/s; 64 KiB / 256 threads / radix-8 steps
+//  -> 2 waves/SIMD, 7.4 G elem/s, against 9.6 for this geometry at the time)
 constexpr int NTT_MAX_TILE_LOG = 11;
 
 struct NttPassParams {
@@ -55,8 +55,7 @@ struct NttPassParams {
     uint32_t cos_out;      // last pass of an inverse transform: multiply natural output i by h^-i * N^-1 (folded into cos_hi)
     uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
-    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores (wrong results);
-                           // bit3 stagger the second workgroup per CU, bit4 stage twiddles before the data loads (results stay correct)
+    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores (results are wrong)
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -94,7 +93,9 @@ __device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
 }
 
 // One work-item: 2^K elements, K stages in registers.
-template <class F, int K, bool LAST, int TILE>
+// EXTRA: the pass carries a coset scaling or the N^-1 factor (kept out of the plain transform's code: the last-pass
+// kernel is ~60 KiB of straight-line MAC chains and shares a 64 KiB instruction cache with its neighbour CU)
+template <class F, int K, bool LAST, int TILE, bool EXTRA>
 __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step, bool stage_tw) {
@@ -151,7 +152,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
             q1 = lds[1][idx];
         }
         x[j] = unpack_mem<F>(q0, q1);
-        if (step == 0 && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
+        if (EXTRA && step == 0 && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
             const uint64_t e = (LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c)) & p.in_mask;
             Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, e & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, e >> p.cos_hbits));
             x[j] = fe_mul<F>(x[j], pw);
@@ -224,7 +225,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
     }
 
-    if (LAST && last_step && p.cos_out) {   // interpolate_offset_fft: N^-1 and h^-i in one product
+    if (EXTRA && LAST && last_step && p.cos_out) {   // interpolate_offset_fft: N^-1 and h^-i in one product
 #pragma unroll
         for (int j = 0; j < E; j++) {
             const uint32_t m = mbase | ((uint32_t)j << sh);
@@ -233,7 +234,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
             if (F::LAZY) x[j] = fe_cond_sub_kp<F, 0>(fe_mul_lazy<F>(pw, x[j]));
             else x[j] = fe_mul<F>(x[j], pw);
         }
-    } else if (last_step && p.scale) {
+    } else if (EXTRA && last_step && p.scale) {
         Fe<F> sc;
 #pragma unroll
         for (int i = 0; i < 8; i++) sc.v[i] = p.sc[i];
@@ -258,7 +259,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     }
 }
 
-template <class F, bool LAST, class CFG>
+template <class F, bool LAST, class CFG, bool EXTRA>
 __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_kernel(NttPassParams p) {
     constexpr int NTT_THREADS = CFG::THREADS;
     constexpr int NTT_KMAX = CFG::KMAX;
@@ -286,10 +287,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
 
     // twiddle staging happens inside the first register step when every thread runs it (the usual case);
     // tiles with fewer items than threads (small transforms) stage up front
-    const bool stage_inside = !LAST && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS && !(p.dbg & 16);
-    if ((p.dbg & 8) && blockIdx.x >= 256 && blockIdx.x < 512) {   // diagnostics: stagger the second workgroup of each CU
-        for (int i = 0; i < 4; i++) __builtin_amdgcn_s_sleep(127);
-    }
+    const bool stage_inside = !LAST && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS;
     if (!LAST && !stage_inside) {
         // stage t of the pass uses T[(hi << t) | x], x < 2^t, shared by every column of the tile
         for (uint32_t i = tid; i + 1 < (1u << r); i += NTT_THREADS) {
@@ -307,9 +305,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
-            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
-            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
-            else ntt_item<F, 1, LAST, NTT_TILE>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else ntt_item<F, 1, LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
         }
         t0 += k;
     }
