@@ -172,18 +172,35 @@ __device__ __forceinline__ uint32_t lw_k(uint32_t x) {
 #else
 inline uint32_t lw_k(uint32_t x) { return x; }
 #endif
+#if defined(__clang__)
+#define LW_ADDC(a, b, c) __builtin_addc((a), (b), (c), &(c))
+#define LW_SUBC(a, b, c) __builtin_subc((a), (b), (c), &(c))
+#else   // the host-only sanitizer build of this header uses g++
+static inline uint32_t lw_addc_portable(uint32_t a, uint32_t b, unsigned &c) {
+    const uint64_t t = (uint64_t)a + b + c;
+    c = (unsigned)(t >> 32);
+    return (uint32_t)t;
+}
+static inline uint32_t lw_subc_portable(uint32_t a, uint32_t b, unsigned &c) {
+    const uint64_t t = (uint64_t)a - b - c;
+    c = (unsigned)((t >> 32) & 1);
+    return (uint32_t)t;
+}
+#define LW_ADDC(a, b, c) lw_addc_portable((a), (b), (c))
+#define LW_SUBC(a, b, c) lw_subc_portable((a), (b), (c))
+#endif
 template <int N>
 LW_HD uint32_t limbs_add(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
     unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) r[i] = __builtin_addc(a[i], b[i], c, &c);
+    for (int i = 0; i < N; i++) r[i] = LW_ADDC(a[i], b[i], c);
     return c;
 }
 template <int N>
 LW_HD uint32_t limbs_sub(uint32_t (&r)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
     unsigned c = 0;
 #pragma unroll
-    for (int i = 0; i < N; i++) r[i] = __builtin_subc(a[i], b[i], c, &c);
+    for (int i = 0; i < N; i++) r[i] = LW_SUBC(a[i], b[i], c);
     return c;
 }
 // limb i of K*p for K = 2^LOGK

@@ -64,29 +64,52 @@ __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint6
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
 }
 
-// pass A0 (ITEMS == nullptr): coarse histogram.  pass A1: scatter packed items (fine digit << 32 | index) into runs.
+// An item is (fine digit, point index): 32 bits (digit << 24 | index) when the index fits 24 bits, which halves the
+// traffic of the intermediate list at the sizes that matter most (N <= 2^24), else 64 bits (digit << 32 | index).
+template <class ITEM> struct ItemPack;
+template <> struct ItemPack<uint32_t> {
+    static __device__ __forceinline__ uint32_t make(uint32_t fine, uint64_t idx) { return (fine << 24) | (uint32_t)idx; }
+    static __device__ __forceinline__ uint32_t fine(uint32_t it) { return it >> 24; }
+    static __device__ __forceinline__ uint32_t index(uint32_t it) { return it & 0xffffffu; }
+};
+template <> struct ItemPack<uint64_t> {
+    static __device__ __forceinline__ uint64_t make(uint32_t fine, uint64_t idx) { return ((uint64_t)fine << 32) | (uint32_t)idx; }
+    static __device__ __forceinline__ uint32_t fine(uint64_t it) { return (uint32_t)(it >> 32); }
+    static __device__ __forceinline__ uint32_t index(uint64_t it) { return (uint32_t)it; }
+};
+
+// pass A0 (count_only): coarse histogram.  pass A1: scatter packed items into the runs reserved per coarse bin.
+// A workgroup takes `ppb` points.  The scatter is bound by its 4-byte stores into W << (c - 8) runs (the count pass,
+// same loads and LDS atomics without the stores, takes a sixth of the time).
+template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W,
-                                                                 uint32_t fine_bits, uint32_t *coarse_cnt,
-                                                                 const uint32_t *coarse_off, uint32_t *coarse_cursor,
-                                                                 uint64_t *items) {
-    __shared__ uint32_t h[SORT_MAX_COARSE];
+                                                                 uint32_t fine_bits, uint32_t ppb, int count_only,
+                                                                 uint32_t *coarse_cnt, const uint32_t *coarse_off,
+                                                                 uint32_t *coarse_cursor, ITEM *items) {
+    __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
     __shared__ uint32_t base[SORT_MAX_COARSE];
     const uint32_t hb = c - fine_bits, CB = W << hb;
     const uint32_t tid = threadIdx.x;
     for (uint32_t b = tid; b < CB; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
-    const uint64_t p0 = (uint64_t)blockIdx.x * SORT_PTS_PER_BLOCK;
-    const uint64_t p1 = min(n, p0 + SORT_PTS_PER_BLOCK);
+    const uint64_t p0 = (uint64_t)blockIdx.x * ppb;
+    const uint64_t p1 = min(n, p0 + ppb);
+    // zero digits go to a dummy slot so that the LDS atomics of a scalar's windows are issued back to back
+    // (no branch between them); four windows are in flight before any result is consumed
     for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
         uint32_t s[8];
         load_scalar_words(scalars, i, s);
-        for (uint32_t w = 0; w < W; w++) {
-            uint32_t d = scalar_digit(s, w, c);
-            if (d) atomicAdd(&h[(w << hb) | (d >> fine_bits)], 1u);
+        for (uint32_t w0 = 0; w0 < W; w0 += 4) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t w = w0 + j;
+                const uint32_t d = w < W ? scalar_digit(s, w, c) : 0u;
+                atomicAdd(&h[d ? ((w << hb) | (d >> fine_bits)) : SORT_MAX_COARSE], 1u);
+            }
         }
     }
     __syncthreads();
-    if (!items) {
+    if (count_only) {
         for (uint32_t b = tid; b < CB; b += SORT_THREADS)
             if (h[b]) atomicAdd(&coarse_cnt[b], h[b]);
         return;
@@ -100,19 +123,29 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
     for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
         uint32_t s[8];
         load_scalar_words(scalars, i, s);
-        for (uint32_t w = 0; w < W; w++) {
-            uint32_t d = scalar_digit(s, w, c);
-            if (d) {
-                uint32_t b = (w << hb) | (d >> fine_bits);
-                uint32_t r = atomicAdd(&h[b], 1u);
-                items[base[b] + r] = ((uint64_t)(d & ((1u << fine_bits) - 1)) << 32) | (uint32_t)i;
+        for (uint32_t w0 = 0; w0 < W; w0 += 4) {
+            uint32_t d[4], b[4], r[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t w = w0 + j;
+                d[j] = w < W ? scalar_digit(s, w, c) : 0u;
+                b[j] = d[j] ? ((w << hb) | (d[j] >> fine_bits)) : SORT_MAX_COARSE;
             }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) r[j] = atomicAdd(&h[b[j]], 1u);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                if (d[j]) items[base[b[j]] + r[j]] = ItemPack<ITEM>::make(d[j] & ((1u << fine_bits) - 1), i);
         }
     }
 }
 
-// pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen
-__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const uint64_t *items, const uint32_t *coarse_off, uint32_t fine_bits,
+// pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen.
+// Both sweeps over the bin issue FINE_UNROLL independent loads per work-item before touching LDS: the kernel is bound
+// by memory latency (VALUBusy 2 %), not by the LDS atomics.
+constexpr int FINE_UNROLL = 4;
+template <class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, uint32_t fine_bits,
                                                                uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen) {
     __shared__ uint32_t h[1 << SORT_FINE_BITS];
     __shared__ uint32_t pre[1 << SORT_FINE_BITS];
@@ -120,7 +153,17 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const uint64_t *
     const uint32_t i0 = coarse_off[b], i1 = coarse_off[b + 1];
     if (tid < FB) h[tid] = 0;
     __syncthreads();
-    for (uint32_t i = i0 + tid; i < i1; i += SORT_THREADS) atomicAdd(&h[(uint32_t)(items[i] >> 32)], 1u);
+    for (uint32_t i = i0 + tid; i < i1; i += FINE_UNROLL * SORT_THREADS) {
+        ITEM it[FINE_UNROLL];
+#pragma unroll
+        for (int j = 0; j < FINE_UNROLL; j++) {
+            const uint32_t k = i + j * SORT_THREADS;
+            it[j] = k < i1 ? items[k] : (ITEM)0;
+        }
+#pragma unroll
+        for (int j = 0; j < FINE_UNROLL; j++)
+            if (i + j * SORT_THREADS < i1) atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
+    }
     __syncthreads();
     // exclusive scan of the FB (<= 256) counts
     uint32_t v = tid < FB ? h[tid] : 0;
@@ -143,10 +186,20 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const uint64_t *
         pre[tid] = i0 + excl;   // running cursor per fine digit
     }
     __syncthreads();
-    for (uint32_t i = i0 + tid; i < i1; i += SORT_THREADS) {
-        uint64_t it = items[i];
-        uint32_t pos = atomicAdd(&pre[(uint32_t)(it >> 32)], 1u);
-        sorted[pos] = (uint32_t)it;
+    for (uint32_t i = i0 + tid; i < i1; i += FINE_UNROLL * SORT_THREADS) {
+        ITEM it[FINE_UNROLL];
+#pragma unroll
+        for (int j = 0; j < FINE_UNROLL; j++) {
+            const uint32_t k = i + j * SORT_THREADS;
+            it[j] = k < i1 ? items[k] : (ITEM)0;
+        }
+#pragma unroll
+        for (int j = 0; j < FINE_UNROLL; j++) {
+            if (i + j * SORT_THREADS < i1) {
+                uint32_t pos = atomicAdd(&pre[ItemPack<ITEM>::fine(it[j])], 1u);
+                sorted[pos] = ItemPack<ITEM>::index(it[j]);
+            }
+        }
     }
 }
 
@@ -253,26 +306,38 @@ uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W) {
     const uint32_t fine = c < SORT_FINE_BITS ? c : SORT_FINE_BITS;
     return W << (c - fine);
 }
+template <class ITEM>
+static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t fine, uint32_t CB,
+                          uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items, uint32_t *sorted,
+                          uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
+    const uint32_t ppb = SORT_PTS_PER_BLOCK;   // 4096 points per workgroup (longer runs per bin) measured no faster
+    const uint32_t blocks = (uint32_t)((n + ppb - 1) / ppb);
+    hipEvent_t pe = c.prof_begin(s);
+    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, ppb, 1, coarse_cnt,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (ITEM *)nullptr);
+    c.prof_end("msm_coarse_kernel<count>", pe, s);
+    msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, ppb, 0, coarse_cnt,
+                       (const uint32_t *)coarse_off, coarse_cursor, items);
+    c.prof_end("msm_coarse_kernel<scatter>", pe, s);
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL((msm_fine_kernel<ITEM>), dim3(CB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
+                       fine, sorted, off, K, maxlen);
+    c.prof_end("msm_fine_kernel", pe, s);
+}
 // coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off: CB + 1; items: n*W u64; off: K + 1; maxlen: zeroed
 void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
     const uint32_t fine = cb < SORT_FINE_BITS ? cb : SORT_FINE_BITS;
     const uint32_t CB = W << (cb - fine);
-    const uint32_t blocks = (uint32_t)((n + SORT_PTS_PER_BLOCK - 1) / SORT_PTS_PER_BLOCK);
-    hipEvent_t pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_coarse_kernel, dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, coarse_cnt,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
-    c.prof_end("msm_coarse_kernel<count>", pe, s);
-    msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
-    pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_coarse_kernel, dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, coarse_cnt,
-                       (const uint32_t *)coarse_off, coarse_cursor, items);
-    c.prof_end("msm_coarse_kernel<scatter>", pe, s);
-    pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_fine_kernel, dim3(CB), dim3(SORT_THREADS), 0, s, (const uint64_t *)items, (const uint32_t *)coarse_off,
-                       fine, sorted, off, K, maxlen);
-    c.prof_end("msm_fine_kernel", pe, s);
+    if (n <= (1ull << 24))
+        launch_sort_t<uint32_t>(c, scalars, n, cb, W, fine, CB, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off, K,
+                                maxlen, scan_tmp, s);
+    else
+        launch_sort_t<uint64_t>(c, scalars, n, cb, W, fine, CB, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
+                                scan_tmp, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {

@@ -150,3 +150,26 @@ def test_msm_over_montgomery_scalars_equals_representative_then_msm(name, fr):
     got = msm.msm_fr(crv, mont, points)
     assert aff(oid, got) == aff(oid, O.msm(oid, canon, points))
     assert aff(oid, got) == aff(oid, msm.msm(crv, canon, points))
+
+
+def test_msm_above_2_24_points_splits_additively():
+    # N > 2^24 takes the 64-bit sort items (index no longer fits the packed 32-bit form) and BASELINE's full size
+    # sits exactly on the boundary: MSM over 2^24 + 4096 pairs must equal MSM(first 2^24) + MSM(last 4096), and the
+    # 2^24 part runs the packed path.  BN254 G1 (96-byte points) keeps the buffers small.
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bn254_g1"]
+    base_n, n_lo, n_hi = 1 << 12, 1 << 24, 1 << 12
+    _, base = util.msm_case(oid, base_n, 21)
+    n = n_lo + n_hi
+    rng = np.random.default_rng(22)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n // base_n, 1)
+    ts = torch.from_numpy(sc.view(np.int64)).cuda()
+    whole = msm.msm_device(crv, ts, tp, n)
+    lo = msm.msm_device(crv, ts[:n_lo], tp[:n_lo], n_lo)
+    hi = msm.msm_device(crv, ts[n_lo:].contiguous(), tp[n_lo:].contiguous(), n_hi)
+    assert aff(oid, O.ec_add(oid, lo, hi)) == aff(oid, whole)
+    # and the small tail agrees with the oracle's Pippenger outright
+    want = O.msm(oid, sc[n_lo:], np.ascontiguousarray(np.tile(base, (n // base_n, 1))[n_lo:]))
+    assert aff(oid, hi) == aff(oid, want)
