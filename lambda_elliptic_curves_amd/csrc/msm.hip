@@ -349,6 +349,10 @@ void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, ui
 }
 size_t msm_scan_scratch_bytes(uint32_t K) { return 8 * (size_t)((K + SCAN_TILE - 1) / SCAN_TILE) + 256; }
 
+uint32_t msm_g_log() {
+    static uint32_t g = [] { const char *e = getenv("LW_HIP_MSM_GLOG"); int v = e ? atoi(e) : 3; return (uint32_t)(v < 1 ? 1 : (v > 6 ? 6 : v)); }();
+    return g;
+}
 int msm_waves_per_simd() {
     static int w = [] { const char *e = getenv("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
     return w;

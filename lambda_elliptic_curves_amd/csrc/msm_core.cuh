@@ -9,7 +9,7 @@
 namespace lw {
 
 constexpr uint32_t MSM_CH = 32;        // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
-constexpr uint32_t MSM_G_LOG = 4;      // buckets per running-sum group (2^4): short dependent chains, many groups
+uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
 // host launchers for the curve-independent kernels (defined in msm.hip)
@@ -149,6 +149,7 @@ struct MsmRunner {
     // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
     static constexpr size_t PB = 3 * C::B::BYTES;
     int reduce(const char *in, uint32_t n, uint32_t nwin, Carver &cv, char **S_out, char **A_out) {
+        const uint32_t MSM_G_LOG = msm_g_log();
         const uint32_t g = 1u << MSM_G_LOG;
         if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
             char *out = (char *)cv.take(PB * 2 * (size_t)nwin);
