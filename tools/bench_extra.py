@@ -66,6 +66,27 @@ def main():
     time_msm("bn254_g1_2^24", "bn254_g1", 24)
     time_msm("bn254_g2_2^22", "bn254_g2", 22)
     time_msm("bls12_381_g2_2^20", "bls12_381_g2", 20)
+    # host-buffer entry points (what a drop-in caller without device residency pays): PCIe copies included
+    a = util.rand_elems("stark252", 1 << 24, 2)
+    fft.evaluate_fft(fp["stark252"][0], a)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fft.evaluate_fft(fp["stark252"][0], a)
+    dt = (time.perf_counter() - t0) / 3
+    out["stark252_fwd_2^24_host_buffers"] = {"ms": dt * 1e3, "elements_per_s": (1 << 24) / dt}
+    print("stark252_fwd_2^24_host_buffers", out["stark252_fwd_2^24_host_buffers"], flush=True)
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    _, base = util.msm_case(oid, 1 << 14, 3)
+    n = 1 << 22
+    pts = np.ascontiguousarray(np.tile(base, (n >> 14, 1)))
+    sc = np.random.default_rng(6).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    msm.msm(crv, sc, pts)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        msm.msm(crv, sc, pts)
+    dt = (time.perf_counter() - t0) / 2
+    out["bls12_381_g1_2^22_host_buffers"] = {"ms": dt * 1e3, "points_per_s": n / dt}
+    print("bls12_381_g1_2^22_host_buffers", out["bls12_381_g1_2^22_host_buffers"], flush=True)
     json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/bench_extra.json", "w"), indent=1)
 
 
