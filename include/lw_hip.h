@@ -210,6 +210,24 @@ int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalar
 int lw_hip_msm_fr_device(lw_curve_t curve, const uint64_t *d_fr_elements, const void *d_points, size_t n,
                          void *out_point_host, void *hip_stream);
 
+/* Fixed point set cached on the device in affine form (SURVEY 8f "next" #2, second half).  Every reference caller
+ * multiplies against a structured reference string it built once: KZG commits with
+ * msm(&coefficients, &srs.powers_main_group[..coefficients.len()]) (crypto/src/commitments/kzg.rs:159-163), Groth16 with
+ * the proving key's l_tau_g1 / r_tau_g1 / ... vectors (provers/groth16/src/prover.rs:69-85).  lw_hip_srs_create uploads
+ * the projective points once, normalises them on the device (the to_affine of short_weierstrass/point.rs:91-129; the
+ * identity is kept as a marked row) and keeps the affine rows resident; lw_hip_msm_srs then runs the same Pippenger
+ * with mixed additions over the first n_scalars points.  Results are identical to lw_hip_msm on the same inputs.
+ * n_scalars may be any length <= the SRS length (the KZG call shape); longer is LW_ERR_LENGTH_MISMATCH. */
+typedef struct lw_srs lw_srs_t;
+int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_srs_t **out_srs);
+int lw_hip_srs_create_device(lw_curve_t curve, const void *d_points, size_t n_points, void *hip_stream, lw_srs_t **out_srs);
+int lw_hip_srs_destroy(lw_srs_t *srs);
+int lw_hip_msm_srs(const lw_srs_t *srs, const uint64_t *scalars, size_t n_scalars, void *out_point);
+int lw_hip_msm_srs_device(const lw_srs_t *srs, const uint64_t *d_scalars, size_t n_scalars, void *out_point_host,
+                          void *hip_stream);
+/* scalars as stored FrElements (Montgomery form), see lw_hip_msm_fr */
+int lw_hip_msm_srs_fr(const lw_srs_t *srs, const uint64_t *fr_elements, size_t n_scalars, void *out_point);
+
 #ifdef __cplusplus
 }
 #endif

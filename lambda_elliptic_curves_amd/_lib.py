@@ -25,6 +25,8 @@ EXPORTS = [
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
     "lw_hip_msm_fr", "lw_hip_msm_fr_device", "lw_groth16_h_coefficients",
     "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
+    "lw_hip_srs_create", "lw_hip_srs_create_device", "lw_hip_srs_destroy", "lw_hip_msm_srs", "lw_hip_msm_srs_device",
+    "lw_hip_msm_srs_fr",
 ]
 
 
@@ -107,6 +109,18 @@ def lib():
     L.lw_hip_msm_fr.restype = i
     L.lw_hip_msm_fr_device.argtypes = [i, vp, vp, sz, vp, vp]
     L.lw_hip_msm_fr_device.restype = i
+    L.lw_hip_srs_create.argtypes = [i, vp, sz, C.POINTER(vp)]
+    L.lw_hip_srs_create.restype = i
+    L.lw_hip_srs_create_device.argtypes = [i, vp, sz, vp, C.POINTER(vp)]
+    L.lw_hip_srs_create_device.restype = i
+    L.lw_hip_srs_destroy.argtypes = [vp]
+    L.lw_hip_srs_destroy.restype = i
+    L.lw_hip_msm_srs.argtypes = [vp, vp, sz, vp]
+    L.lw_hip_msm_srs.restype = i
+    L.lw_hip_msm_srs_fr.argtypes = [vp, vp, sz, vp]
+    L.lw_hip_msm_srs_fr.restype = i
+    L.lw_hip_msm_srs_device.argtypes = [vp, vp, sz, vp, vp]
+    L.lw_hip_msm_srs_device.restype = i
     _lib = L
     return L
 

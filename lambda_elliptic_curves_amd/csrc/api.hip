@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <new>
 #include <vector>
 #include "context.h"
 #include "field.cuh"
@@ -115,7 +116,8 @@ int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
                   uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream, int scalars_montgomery);
+               hipStream_t stream, int scalars_montgomery, int affine_points);
+int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
@@ -543,7 +545,7 @@ static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const v
     if (rc) return rc;
     if (lw_hip_curve_point_bytes(curve) == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
     auto t0 = std::chrono::steady_clock::now();
-    rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream, mont);
+    rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream, mont, 0);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;
@@ -702,7 +704,7 @@ static int msm_host_entry(lw_curve_t curve, const uint64_t *scalars, size_t n_sc
         LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
         LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     }
-    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0, mont);
+    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0, mont, 0);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;
@@ -713,6 +715,90 @@ int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, cons
 int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalars, const void *points, size_t n_points,
                   void *out_point) {
     return msm_host_entry(curve, fr_elements, n_scalars, points, n_points, out_point, 1);
+}
+
+// ---- device-resident affine SRS (see include/lw_hip.h) ----
+}  // extern "C"
+struct lw_srs {
+    lw_curve_t curve;
+    size_t n;
+    lw::DeviceBuf pts;   // n affine rows (2 field elements each), (0,0) = identity
+};
+extern "C" {
+
+static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream_t stream, lw_srs_t **out_srs) {
+    Context &c = ctx();
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    lw_srs *h = new (std::nothrow) lw_srs{curve, n, {}};
+    if (!h) return LW_ERR_ALLOC;
+    if (n && h->pts.ensure(n * (pb / 3) * 2)) { delete h; return LW_ERR_ALLOC; }
+    int rc = n ? msm_normalize_device(c, curve, d_points, n, h->pts.p, stream) : LW_OK;
+    if (rc == LW_OK && n && hipStreamSynchronize(stream) != hipSuccess) { set_error("SRS normalisation failed"); rc = LW_ERR_LAUNCH; }
+    if (rc) { h->pts.release(); delete h; return rc; }
+    *out_srs = h;
+    return LW_OK;
+}
+int lw_hip_srs_create_device(lw_curve_t curve, const void *d_points, size_t n_points, void *hip_stream, lw_srs_t **out_srs) {
+    if (!out_srs || lw_hip_curve_point_bytes(curve) == 0 || (n_points && !d_points)) { set_error("bad curve or null argument"); return LW_ERR_BAD_ARG; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    return srs_build(curve, d_points, n_points, (hipStream_t)hip_stream, out_srs);
+}
+int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_srs_t **out_srs) {
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    if (!out_srs || pb == 0 || (n_points && !points)) { set_error("bad curve or null argument"); return LW_ERR_BAD_ARG; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (n_points) {
+        if (c.host_io_b.ensure(n_points * pb)) return LW_ERR_ALLOC;
+        LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n_points * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+    }
+    return srs_build(curve, c.host_io_b.p, n_points, 0, out_srs);
+}
+int lw_hip_srs_destroy(lw_srs_t *srs) {
+    if (!srs) return LW_OK;
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    srs->pts.release();
+    delete srs;
+    return LW_OK;
+}
+static int msm_srs_entry(const lw_srs_t *srs, const uint64_t *scalars, size_t n, void *out_point, hipStream_t stream, int host_scalars,
+                         int mont) {
+    if (!srs || !out_point) { set_error("null SRS or output"); return LW_ERR_BAD_ARG; }
+    if (n > srs->n) {   // MSMError::LengthMismatch (math/src/msm/pippenger.rs:25-27): more scalars than points
+        set_error("scalars and points have different lengths: %zu vs %zu", n, srs->n);
+        return LW_ERR_LENGTH_MISMATCH;
+    }
+    if (n && !scalars) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    int rc = ensure_init();
+    if (rc) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t *d_scalars = scalars;
+    if (host_scalars && n) {
+        if (c.host_io_a.ensure(n * 32)) return LW_ERR_ALLOC;
+        LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+        d_scalars = (const uint64_t *)c.host_io_a.p;
+    }
+    rc = msm_device(c, srs->curve, d_scalars, srs->pts.p, n, out_point, stream, mont, 1);
+    c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    c.timings.msm_calls++;
+    return rc;
+}
+int lw_hip_msm_srs(const lw_srs_t *srs, const uint64_t *scalars, size_t n_scalars, void *out_point) {
+    return msm_srs_entry(srs, scalars, n_scalars, out_point, 0, 1, 0);
+}
+int lw_hip_msm_srs_fr(const lw_srs_t *srs, const uint64_t *fr_elements, size_t n_scalars, void *out_point) {
+    return msm_srs_entry(srs, fr_elements, n_scalars, out_point, 0, 1, 1);
+}
+int lw_hip_msm_srs_device(const lw_srs_t *srs, const uint64_t *d_scalars, size_t n_scalars, void *out_point_host, void *hip_stream) {
+    return msm_srs_entry(srs, d_scalars, n_scalars, out_point_host, (hipStream_t)hip_stream, 0, 0);
 }
 
 }  // extern "C"

@@ -358,13 +358,18 @@ int msm_waves_per_simd() {
     return w;
 }
 
-int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
-int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
-int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
-int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out);
+int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
+int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
+int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
+int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
+int msm_normalize_bls12381_g1(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
+int msm_normalize_bn254_g1(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
+int msm_normalize_bn254_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
+int msm_normalize_bls12381_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 
+// affine_points: d_points are affine pairs produced by msm_normalize_device (2 field elements per row)
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream, int scalars_montgomery) {
+               hipStream_t stream, int scalars_montgomery, int affine_points) {
     if (scalars_montgomery && n) {
         if (c.msm_scalars.ensure(n * 32)) return LW_ERR_ALLOC;
         const int bn = (curve == LW_CURVE_BN254_G1 || curve == LW_CURVE_BN254_G2);
@@ -375,10 +380,20 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         d_scalars = (const uint64_t *)c.msm_scalars.p;
     }
     switch (curve) {
-        case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host);
-        case LW_CURVE_BN254_G1: return msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host);
-        case LW_CURVE_BN254_G2: return msm_run_bn254_g2(c, stream, d_scalars, d_points, n, out_host);
-        case LW_CURVE_BLS12_381_G2: return msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host);
+        case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host, affine_points);
+        case LW_CURVE_BN254_G1: return msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host, affine_points);
+        case LW_CURVE_BN254_G2: return msm_run_bn254_g2(c, stream, d_scalars, d_points, n, out_host, affine_points);
+        case LW_CURVE_BLS12_381_G2: return msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host, affine_points);
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
+
+int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_normalize_bls12381_g1(c, stream, d_in, n, d_out);
+        case LW_CURVE_BN254_G1: return msm_normalize_bn254_g1(c, stream, d_in, n, d_out);
+        case LW_CURVE_BN254_G2: return msm_normalize_bn254_g2(c, stream, d_in, n, d_out);
+        case LW_CURVE_BLS12_381_G2: return msm_normalize_bls12381_g2(c, stream, d_in, n, d_out);
         default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
     }
 }

@@ -35,7 +35,9 @@ __device__ __forceinline__ void pt_st(void *base, size_t i, const Point<C> &p) {
 //                       empty) -> pout[key], the dense bucket array.
 // index != nullptr: item i is the point pts[index[i]] (first round: the caller's points through the sorted index
 // list); otherwise item i is pts[i] (partial sums of the previous round).
-template <class C, int WAVES>
+// AFFINE: the rows of `pts` are affine pairs of a pre-normalised SRS (lw_hip_srs_*): 2/3 of the bytes per gather and
+// the mixed addition (19 N^2 MACs instead of 21 N^2).  Only first-round launches (index != nullptr) use it.
+template <class C, int WAVES, bool AFFINE>
 __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *pts, const uint32_t *index,
                                                                              const uint32_t *seg_off, const uint32_t *out_off,
                                                                              uint32_t K, uint32_t total_items, void *pout) {
@@ -57,31 +59,57 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
         b = seg_off[t];
         e = seg_off[t + 1];
     }
-    // The gather of a point (144-288 B from a random row) is a dependent chain index -> row.  The next index is
+    // The gather of a point (96-288 B from a random row) is a dependent chain index -> row.  The next index is
     // fetched one addition ahead, and the next row's cache lines are touched (one dword per 128 B, discarded) before
     // the current addition starts, so the real load at the top of the next iteration hits L2.
+    constexpr int PW = (AFFINE ? 2 : 3) * C::B::BYTES / 4;   // row size in dwords
+    auto row_ptr = [&](uint32_t i) { return (const char *)pts + (size_t)i * (PW * 4); };
     Point<C> acc = pt_identity<C>();
     uint32_t idx_next = b;
     if (b < e) {
-        acc = pt_ld<C>(pts, index ? index[b] : b);
+        const uint32_t i0 = index ? index[b] : b;
+        if constexpr (AFFINE) acc = aff_to_point<C>(aff_load<C>(row_ptr(i0)));
+        else acc = pt_load<C>(row_ptr(i0));
         if (b + 1 < e) idx_next = index ? index[b + 1] : b + 1;
     }
-    constexpr int PW = 3 * C::B::BYTES / 4;
 #pragma nounroll
     for (uint32_t i = b + 1; i < e; i++) {
-        Point<C> p = pt_ld<C>(pts, idx_next);
+        const char *cur = row_ptr(idx_next);
         uint32_t touch0 = 0, touch1 = 0, touch2 = 0;
-        if (i + 1 < e) {
-            idx_next = index ? index[i + 1] : i + 1;
-            const uint32_t *row = reinterpret_cast<const uint32_t *>((const char *)pts + (size_t)idx_next * (PW * 4));
-            touch0 = row[0];
-            touch1 = row[32 < PW ? 32 : 0];
-            touch2 = row[PW - 1];
+        if constexpr (AFFINE) {
+            const AffPoint<C> q = aff_load<C>(cur);
+            if (i + 1 < e) {
+                idx_next = index ? index[i + 1] : i + 1;
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next));
+                touch0 = row[0];
+                touch1 = row[32 < PW ? 32 : 0];
+                touch2 = row[PW - 1];
+            }
+            if (!aff_is_identity<C>(q)) acc = pt_add_mixed<C>(acc, q);
+        } else {
+            const Point<C> q = pt_load<C>(cur);
+            if (i + 1 < e) {
+                idx_next = index ? index[i + 1] : i + 1;
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next));
+                touch0 = row[0];
+                touch1 = row[32 < PW ? 32 : 0];
+                touch2 = row[PW - 1];
+            }
+            acc = pt_add<C>(acc, q);
         }
-        acc = pt_add<C>(acc, p);
         asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // consume the touches after the MACs
     }
     pt_st<C>(pout, t, acc);
+}
+
+// SRS preparation: projective rows -> affine pairs, one Fermat inversion per point (a one-off per SRS, so the
+// simple form is used rather than a batch inversion)
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, void *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffPoint<C> a = pt_to_aff<C>(pt_load<C>((const char *)in + i * (3 * C::B::BYTES)));
+    aff_store<C>((char *)out + i * (2 * C::B::BYTES), a);
 }
 
 // ---------------------------------------------------------------- bucket reduce
@@ -145,6 +173,18 @@ struct MsmRunner {
     Context &c;
     hipStream_t stream;
     uint32_t W;
+    bool affine = false;   // d_points are affine pairs (pre-normalised SRS)
+
+    // SRS preparation (lw_hip_srs_create*): n projective rows -> n affine pairs
+    int normalize(const void *d_in, size_t n, void *d_out) {
+        if (!n) return LW_OK;
+        hipEvent_t pe = c.prof_begin(stream);
+        hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, stream,
+                           d_in, (uint64_t)n, d_out);
+        c.prof_end("msm_to_affine_kernel", pe, stream);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
 
     // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
     static constexpr size_t PB = 3 * C::B::BYTES;
@@ -229,12 +269,15 @@ struct MsmRunner {
                 if (total) {
                     const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
                     hipEvent_t pe = c.prof_begin(stream);
-                    if (msm_waves_per_simd() == 3)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                           (const uint32_t *)out_off, K, total, (void *)pout);
+                    if (index && affine)
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
+                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
+                    else if (msm_waves_per_simd() == 3)
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
+                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
                     else
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                           (const uint32_t *)out_off, K, total, (void *)pout);
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
+                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
                     c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
                 }
             }
@@ -248,8 +291,12 @@ struct MsmRunner {
         if (!dry) {
             const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_accumulate_kernel<C, 2>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                               (const uint32_t *)nullptr, K, K, (void *)buckets);
+            if (index && affine)
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                   (const uint32_t *)nullptr, K, K, (void *)buckets);
+            else
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                   (const uint32_t *)nullptr, K, K, (void *)buckets);
             c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
         }
         char *A_unused;

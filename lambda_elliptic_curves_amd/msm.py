@@ -62,3 +62,57 @@ def msm_device(curve, t_scalars, t_points, n, stream=None):
     check(L.lib().lw_hip_msm_device(curve.curve, C.c_void_p(t_scalars.data_ptr()), C.c_void_p(t_points.data_ptr()), n,
                                     out.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
     return out
+
+
+class Srs:
+    """A fixed point set kept on the device in affine form (lw_hip_srs_*): what the reference's KZG
+    `StructuredReferenceString.powers_main_group` (crypto/src/commitments/kzg.rs:159-163) or a Groth16 proving-key
+    vector (provers/groth16/src/prover.rs:69-85) is to repeated msm() calls.  `srs.msm(cs)` equals
+    msm(cs, points[:len(cs)]) — fewer scalars than points is the KZG call shape; more is LengthMismatch."""
+
+    def __init__(self, curve, points=None, t_points=None, n=None, stream=None):
+        self.curve = curve
+        self._h = C.c_void_p()
+        if t_points is not None:        # device-resident projective points (torch tensor)
+            import torch
+            if stream is None:
+                stream = torch.cuda.current_stream().cuda_stream
+            self.n = int(n if n is not None else t_points.shape[0])
+            check(L.lib().lw_hip_srs_create_device(curve.curve, C.c_void_p(t_points.data_ptr()), self.n, C.c_void_p(stream),
+                                                   C.byref(self._h)))
+        else:
+            p = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, curve.point_words)
+            self.n = p.shape[0]
+            check(L.lib().lw_hip_srs_create(curve.curve, p.ctypes.data_as(C.c_void_p), self.n, C.byref(self._h)))
+
+    def msm(self, cs):
+        s = np.ascontiguousarray(cs, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(self.curve.point_words, dtype=np.uint64)
+        check(L.lib().lw_hip_msm_srs(self._h, s.ctypes.data_as(C.c_void_p), s.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def msm_fr(self, fr_elements):
+        s = np.ascontiguousarray(fr_elements, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(self.curve.point_words, dtype=np.uint64)
+        check(L.lib().lw_hip_msm_srs_fr(self._h, s.ctypes.data_as(C.c_void_p), s.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def msm_device(self, t_scalars, n, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        out = np.zeros(self.curve.point_words, dtype=np.uint64)
+        check(L.lib().lw_hip_msm_srs_device(self._h, C.c_void_p(t_scalars.data_ptr()), n, out.ctypes.data_as(C.c_void_p),
+                                            C.c_void_p(stream)))
+        return out
+
+    def close(self):
+        if self._h:
+            L.lib().lw_hip_srs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -8,7 +8,7 @@ from oracle import oracle as O
 def test_synthetic_bls12381_points_are_distinct_curve_points_with_z_not_one():
     pts = bench_msm.synth_points_bls12381_g1(256, 7)
     assert pts.shape == (256, 18) and pts.dtype == np.uint64
-    one = O.elems_to_mont(O.F_FP381, np.array([[0, 0, 0, 0, 0, 1]], dtype=np.uint64))[0]
+    one = O.int_to_limbs(O.field_params(O.F_FP381)["one"], 6)       # Montgomery form of 1
     p = bench_msm.BLS_P
     seen = set()
     for row in pts:

@@ -1,0 +1,109 @@
+"""GPU parity for the device-resident affine SRS (lw_hip_srs_* / lw_hip_msm_srs): the same group element as
+msm(cs, points[:len(cs)]) — checked against the CPU oracle's Pippenger (math/src/msm/pippenger.rs:18-103) and against
+the projective HIP path, including the cases only a mixed-addition path can get wrong (identity rows in the SRS,
+P and -P, repeated points, everything in one bucket)."""
+import numpy as np
+import pytest
+
+from oracle import bigint_def as D
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+CURVES = ["bls12_381_g1", "bn254_g1", "bn254_g2", "bls12_381_g2"]
+
+
+def aff(oid, p):
+    return O.point_to_affine_ints(oid, p)
+
+
+@pytest.mark.parametrize("name", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 17, 100, 1000])
+def test_srs_msm_matches_reference_algorithm(name, n):
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 300 + n)
+    srs = msm.Srs(crv, points)
+    got = srs.msm(scalars)
+    exp = O.msm(oid, scalars, points)
+    assert aff(oid, got) == aff(oid, exp)
+    assert aff(oid, got) == aff(oid, msm.msm(crv, scalars, points))
+    srs.close()
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 1 << 14), ("bn254_g1", 1 << 13), ("bn254_g2", 1 << 11), ("bls12_381_g2", 1 << 10)])
+def test_srs_prefix_is_the_kzg_call_shape(name, n):
+    # kzg.rs:159-163: msm(&coefficients, &srs.powers_main_group[..coefficients.len()])
+    from lambda_elliptic_curves_amd import errors, msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 41)
+    srs = msm.Srs(crv, points)
+    for m in (n, n - 1, n // 3, 1, 0):
+        got = srs.msm(scalars[:m])
+        exp = O.parallel_msm_with(oid, scalars[:m], points[:m], max(2, O.optimum_window_size(max(m, 1))), 16) if m else O.ec_neutral(oid)
+        assert aff(oid, got) == aff(oid, exp)
+    with pytest.raises(errors.LengthMismatch):       # more scalars than points (pippenger.rs:25-27)
+        srs.msm(np.concatenate([scalars, scalars[:1]]))
+    srs.close()
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_g1", "bn254_g2"])
+def test_srs_edge_cases(name):
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    g = util.generator(oid)
+    neutral = O.ec_neutral(oid)
+    r = D.P_FR381 if name == "bls12_381_g1" else D.P_FR254
+    p = O.ec_mul(oid, g, 12345, 1)
+    # identity rows inside the SRS (first, middle, last), duplicates, P and -P in one bucket, zero scalars, r-1, 2^256-1
+    pts = np.stack([neutral, p, p, O.ec_neg(oid, p), neutral, g, g, p, neutral])
+    ks = [5, 7, 7, 7, 99, r - 1, 0, (1 << 256) - 1, 3]
+    srs = msm.Srs(crv, pts)
+    got = srs.msm(O.ints_to_array(ks, 4))
+    assert aff(oid, got) == aff(oid, O.msm(oid, O.ints_to_array(ks, 4), pts))
+    # a bucket whose first row is the identity, and a sum that cancels to the identity
+    pts2 = np.stack([neutral, p, O.ec_neg(oid, p)])
+    srs2 = msm.Srs(crv, pts2)
+    assert aff(oid, srs2.msm(O.ints_to_array([9, 9, 9], 4))) is None
+    # an SRS of identities only, and the empty SRS
+    srs3 = msm.Srs(crv, np.stack([neutral, neutral]))
+    assert aff(oid, srs3.msm(O.ints_to_array([1, 2], 4))) is None
+    srs4 = msm.Srs(crv, np.zeros((0, crv.point_words), np.uint64))
+    assert np.array_equal(srs4.msm(np.zeros((0, 4), np.uint64)), neutral)
+
+
+def test_srs_all_points_equal_and_single_bucket():
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 3000
+    scalars, points = util.msm_case(oid, n, 6)
+    pts = np.tile(points[0], (n, 1))                 # P + P inside every bucket chain (complete formula needed)
+    srs = msm.Srs(crv, pts)
+    tot = sum(O.array_to_ints(scalars))
+    assert aff(oid, srs.msm(scalars)) == aff(oid, O.ec_mul(oid, points[0], tot, 5))
+    k = 0x1234567890abcdef1234567890abcdef1234567890abcdef1234567890abcdef
+    same = np.tile(O.int_to_limbs(k, 4), (n, 1))     # every point in the same bucket of every window
+    srs2 = msm.Srs(crv, points)
+    assert aff(oid, srs2.msm(same)) == aff(oid, msm.msm(crv, same, points))
+
+
+def test_srs_device_resident_large_and_montgomery_scalars():
+    # 2^20 points built on the device from a tiled run; SRS path == projective path on the same inputs
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n, base_n = 1 << 20, 1 << 12
+    _, base = util.msm_case(oid, base_n, 77)
+    tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n // base_n, 1)
+    rng = np.random.default_rng(78)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    ts = torch.from_numpy(sc.view(np.int64)).cuda()
+    srs = msm.Srs(crv, t_points=tp, n=n)
+    got = srs.msm_device(ts, n)
+    assert aff(oid, got) == aff(oid, msm.msm_device(crv, ts, tp, n))
+    # FrElements as stored (Montgomery form): representative() on the device, then the SRS MSM
+    m = 1 << 10
+    vals = [k % D.P_FR381 for k in O.array_to_ints(sc[:m])]
+    fr = O.elems_to_mont(O.F_FR381, vals)
+    small = msm.Srs(crv, base[:m])
+    assert aff(oid, small.msm_fr(fr)) == aff(oid, O.msm(oid, O.ints_to_array(vals, 4), base[:m]))

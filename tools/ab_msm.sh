@@ -18,4 +18,11 @@ for name, crv, L in (("bls12381_g1", msm.BLS12381Curve, 24), ("bls12381_g1", msm
     for _ in range(3): msm.msm_device(crv, t_sc, t_pts, n)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3; prof = _lib.profile_end()
     print(name, L, round(dt * 1e3, 3), {k: round(v[1] / max(v[0], 1), 3) for k, v in prof.items()})
+    t0 = time.perf_counter(); srs = msm.Srs(crv, t_points=t_pts, n=n); torch.cuda.synchronize(); t_create = time.perf_counter() - t0
+    srs.msm_device(t_sc, n); torch.cuda.synchronize()
+    _lib.profile_begin(); t0 = time.perf_counter()
+    for _ in range(3): srs.msm_device(t_sc, n)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3; prof = _lib.profile_end()
+    print(name, L, "affine SRS:", round(dt * 1e3, 3), "create", round(t_create * 1e3, 1), {k: round(v[1] / max(v[0], 1), 3) for k, v in prof.items() if "accumulate" in k})
+    srs.close()
 PY

@@ -66,6 +66,26 @@ def main():
     time_msm("bn254_g1_2^24", "bn254_g1", 24)
     time_msm("bn254_g2_2^22", "bn254_g2", 22)
     time_msm("bls12_381_g2_2^20", "bls12_381_g2", 20)
+    # device-resident affine SRS (lw_hip_srs_*): one-off normalisation, then mixed-addition MSMs
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 1 << 24
+    _, base = util.msm_case(oid, 1 << 14, 3)
+    tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n >> 14, 1)
+    ts = torch.from_numpy((np.random.default_rng(5).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2)).view(np.int64)).cuda()
+    t0 = time.perf_counter()
+    srs = msm.Srs(crv, t_points=tp, n=n)
+    t_create = time.perf_counter() - t0
+    srs.msm_device(ts, n)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        srs.msm_device(ts, n)
+    dt = (time.perf_counter() - t0) / 2
+    out["bls12_381_g1_2^24_affine_srs"] = {"ms": dt * 1e3, "points_per_s": n / dt, "srs_create_ms": t_create * 1e3}
+    print("bls12_381_g1_2^24_affine_srs", out["bls12_381_g1_2^24_affine_srs"], flush=True)
+    srs.close()
+    del tp, ts
+    torch.cuda.empty_cache()
+
     # host-buffer entry points (what a drop-in caller without device residency pays): PCIe copies included
     a = util.rand_elems("stark252", 1 << 24, 2)
     fft.evaluate_fft(fp["stark252"][0], a)
