@@ -126,8 +126,10 @@ struct Fp2Ops {
 };
 
 // ---------------------------------------------------------------- curves (b3 = 3*b)
+// ACC_WAVES: waves per SIMD the MSM accumulate kernel is register-budgeted for
 struct Bls12381G1 {   // y^2 = x^3 + 4   (bls12_381/curve.rs:38-46)
     using B = FpOps<Fp381>;
+    static constexpr int ACC_WAVES = 2;
     LW_HD static B::T mul_b3(const B::T &x) {   // 12x
         B::T x4 = B::dbl(B::dbl(x));
         return B::add(B::dbl(x4), x4);
@@ -135,12 +137,14 @@ struct Bls12381G1 {   // y^2 = x^3 + 4   (bls12_381/curve.rs:38-46)
 };
 struct Bn254G1 {      // y^2 = x^3 + 3   (bn_254/curve.rs:32-40)
     using B = FpOps<Fp254>;
+    static constexpr int ACC_WAVES = 2;
     LW_HD static B::T mul_b3(const B::T &x) {   // 9x
         return B::add(B::dbl(B::dbl(B::dbl(x))), x);
     }
 };
 struct Bls12381G2 {   // y^2 = x^3 + 4(1+u)   (bls12_381/twist.rs:40-48)
     using B = Fp2Ops<Fp381>;
+    static constexpr int ACC_WAVES = 2;   // 256 VGPRs + 77 spilled; a 1-wave budget (322 VGPRs, no spills) measured 15 % slower
     LW_HD static B::T mul_b3(const B::T &x) {   // 12(1+u) * (x0 + x1 u) = 12(x0 - x1) + 12(x0 + x1) u
         Fe<Fp381> d = fe_sub<Fp381>(x.c0, x.c1), s = fe_add<Fp381>(x.c0, x.c1);
         Fe<Fp381> d4 = fe_dbl<Fp381>(fe_dbl<Fp381>(d)), s4 = fe_dbl<Fp381>(fe_dbl<Fp381>(s));
@@ -149,6 +153,7 @@ struct Bls12381G2 {   // y^2 = x^3 + 4(1+u)   (bls12_381/twist.rs:40-48)
 };
 struct Bn254G2 {      // y^2 = x^3 + 3/(9+u)   (bn_254/twist.rs:46-61); 3b' precomputed, Montgomery form
     using B = Fp2Ops<Fp254>;
+    static constexpr int ACC_WAVES = 2;
     LW_HD static constexpr uint32_t b3c0(int i) {
         constexpr uint32_t t[8] = {0xb62e0d6au, 0x3baa927cu, 0xd1b664fdu, 0xd71e7c52u, 0xd95d4664u, 0x03873e63u, 0x082ab8f4u, 0x0e75b5b1u};
         return t[i];

@@ -270,13 +270,13 @@ struct MsmRunner {
                     const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
                     hipEvent_t pe = c.prof_begin(stream);
                     if (index && affine)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
                                            seg, (const uint32_t *)out_off, K, total, (void *)pout);
-                    else if (msm_waves_per_simd() == 3)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 3, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
-                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
+                    else if (C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::ACC_WAVES == 2 ? 3 : C::ACC_WAVES), false>), dim3(blocks),
+                                           dim3(MSM_THREADS), 0, stream, pts, index, seg, (const uint32_t *)out_off, K, total, (void *)pout);
                     else
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
+                        hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
                                            seg, (const uint32_t *)out_off, K, total, (void *)pout);
                     c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
                 }
@@ -292,10 +292,10 @@ struct MsmRunner {
             const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(stream);
             if (index && affine)
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
                                    (const uint32_t *)nullptr, K, K, (void *)buckets);
             else
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, 2, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
                                    (const uint32_t *)nullptr, K, K, (void *)buckets);
             c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
         }
