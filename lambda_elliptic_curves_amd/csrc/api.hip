@@ -68,11 +68,9 @@ Context &ctx() {
 }
 
 void ntt_set_max_pass_stages(uint32_t r);
-void ntt_set_config(int cfg);
 void ntt_set_debug(uint32_t d);
 
 static int init_locked(Context &c, const int *device_ids, int n_devices) {
-    if (const char *e = getenv("LW_HIP_NTT_CFG")) ntt_set_config(atoi(e));
     if (const char *e = getenv("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));
     if (const char *e = getenv("LW_HIP_NTT_MAX_R")) ntt_set_max_pass_stages((uint32_t)atoi(e));
     int count = 0;

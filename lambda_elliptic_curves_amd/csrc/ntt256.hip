@@ -119,7 +119,6 @@ static void split_steps(uint32_t r, NttPassParams &p) {
 
 static uint32_t g_ntt_max_r = 8;
 void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
-void ntt_set_config(int) {}   // alternative geometries were measured and removed (ntt_kernels.cuh)
 
 template <class F, class CFG>
 static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassParams &p) {
