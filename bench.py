@@ -34,6 +34,19 @@ def rand_field_elems(n, seed, top_bits=59):
     return a
 
 
+def pmc_valu_busy(kernel_substr):
+    """Mean VALUBusy (%) of a kernel from the committed rocprofv3 counter summary, or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    try:
+        rows = [r for r in csv.DictReader(open(path)) if r["counter"] == "VALUBusy" and kernel_substr in r["kernel"]]
+        tot = sum(float(r["mean_per_launch"]) * int(r["launches"]) for r in rows)
+        cnt = sum(int(r["launches"]) for r in rows)
+        return tot / cnt if cnt else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +179,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "note": "256-bit NTT is integer-VALU bound (see 'valu'); HBM fraction reported as required"},
             "valu": {"modmul_per_s": (n // 2) * L * args.steps * world / dt, "unit": "Montgomery products/s",
-                     "peak_measured": 182.5e9, "peak_source": "profiles/r01_microbench.txt (fe_mul Stark252, all CUs)"},
+                     "peak_measured": 182.5e9 * world, "peak_source": "profiles/r01_microbench.txt (fe_mul Stark252, all CUs)",
+                     "frac": (n // 2) * L * args.steps / dt / 182.5e9,
+                     "valu_busy_pmc": pmc_valu_busy("ntt_pass_kernel"),
+                     "note": "the bound that applies: products/s against the measured product rate of the MAC pipe; "
+                             "valu_busy_pmc = rocprofv3 VALUBusy (%) from profiles/r01_pmc_summary.csv"},
             "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
         })
         del t_in, t_out
