@@ -102,14 +102,44 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
     pt_st<C>(pout, t, acc);
 }
 
-// SRS preparation: projective rows -> affine pairs, one Fermat inversion per point (a one-off per SRS, so the
-// simple form is used rather than a batch inversion)
+// SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
+// FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks a run of CHK points, stores the running
+// products of their z in the (not yet final) x slots of the output, inverts the last product once (Fermat), and walks
+// back peeling one inverse per point — 3 products per point plus 1/CHK of an inversion instead of a full inversion each.
+// Identity rows (z = 0) are left out of the product and written as (0, 0).
+constexpr uint32_t MSM_AFF_CHK = 32;
 template <class C>
 __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, void *out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const AffPoint<C> a = pt_to_aff<C>(pt_load<C>((const char *)in + i * (3 * C::B::BYTES)));
-    aff_store<C>((char *)out + i * (2 * C::B::BYTES), a);
+    using B = typename C::B;
+    using T = typename B::T;
+    constexpr size_t PBY = 3 * B::BYTES, ABY = 2 * B::BYTES;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t first = t * MSM_AFF_CHK;
+    if (first >= n) return;
+    const uint64_t last = (first + MSM_AFF_CHK < n ? first + MSM_AFF_CHK : n);   // exclusive
+    const char *pin = (const char *)in;
+    char *pout = (char *)out;
+    T acc = B::one();
+#pragma nounroll
+    for (uint64_t i = first; i < last; i++) {
+        const T z = B::load(pin + i * PBY + 2 * B::BYTES);
+        if (!B::is_zero(z)) acc = B::mul(acc, z);
+        B::store(pout + i * ABY, acc);            // running product through point i
+    }
+    T inv = B::inv(acc);                          // acc != 0: a product of non-zero field elements (or one)
+#pragma nounroll
+    for (uint64_t i = last; i-- > first;) {
+        const T z = B::load(pin + i * PBY + 2 * B::BYTES);
+        if (B::is_zero(z)) {
+            aff_store<C>(pout + i * ABY, AffPoint<C>{B::zero(), B::zero()});
+            continue;
+        }
+        const T prev = i == first ? B::one() : B::load(pout + (i - 1) * ABY);
+        const T zinv = B::mul(inv, prev);         // 1 / z_i
+        inv = B::mul(inv, z);                     // 1 / (running product through point i-1)
+        const T x = B::load(pin + i * PBY), y = B::load(pin + i * PBY + B::BYTES);
+        aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(y, zinv)});
+    }
 }
 
 // ---------------------------------------------------------------- bucket reduce
@@ -179,8 +209,9 @@ struct MsmRunner {
     int normalize(const void *d_in, size_t n, void *d_out) {
         if (!n) return LW_OK;
         hipEvent_t pe = c.prof_begin(stream);
-        hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, stream,
-                           d_in, (uint64_t)n, d_out);
+        const uint64_t items = (n + MSM_AFF_CHK - 1) / MSM_AFF_CHK;
+        hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                           stream, d_in, (uint64_t)n, d_out);
         c.prof_end("msm_to_affine_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         return LW_OK;

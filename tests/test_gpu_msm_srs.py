@@ -107,3 +107,22 @@ def test_srs_device_resident_large_and_montgomery_scalars():
     fr = O.elems_to_mont(O.F_FR381, vals)
     small = msm.Srs(crv, base[:m])
     assert aff(oid, small.msm_fr(fr)) == aff(oid, O.msm(oid, O.ints_to_array(vals, 4), base[:m]))
+
+
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_g2"])
+def test_srs_identity_rows_across_batch_inversion_runs(name):
+    # the normalisation inverts z in runs of 32 points; identity rows (z = 0) at the run boundaries must neither
+    # poison a run's product nor shift its neighbours
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    n = 100
+    scalars, points = util.msm_case(oid, n, 91)
+    neutral = O.ec_neutral(oid)
+    for i in (0, 31, 32, 33, 63, 64, 95, 96, 99):
+        points[i] = neutral
+    srs = msm.Srs(crv, points)
+    assert aff(oid, srs.msm(scalars)) == aff(oid, O.msm(oid, scalars, points))
+    ones = np.zeros((n, 4), np.uint64)
+    ones[:, 3] = 1                                   # plain sum of the rows: every normalised row is used as is
+    assert aff(oid, srs.msm(ones)) == aff(oid, O.msm(oid, ones, points))
+    srs.close()
