@@ -103,20 +103,19 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
 }
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
-// FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks a run of CHK points, stores the running
+// FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks a run of `chk` points, stores the running
 // products of their z in the (not yet final) x slots of the output, inverts the last product once (Fermat), and walks
-// back peeling one inverse per point — 3 products per point plus 1/CHK of an inversion instead of a full inversion each.
+// back peeling one inverse per point — 3 products per point plus 1/chk of an inversion instead of a full inversion each.
 // Identity rows (z = 0) are left out of the product and written as (0, 0).
-constexpr uint32_t MSM_AFF_CHK = 32;
 template <class C>
-__global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, void *out) {
+__global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, uint32_t chk, void *out) {
     using B = typename C::B;
     using T = typename B::T;
     constexpr size_t PBY = 3 * B::BYTES, ABY = 2 * B::BYTES;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t first = t * MSM_AFF_CHK;
+    const uint64_t first = t * chk;
     if (first >= n) return;
-    const uint64_t last = (first + MSM_AFF_CHK < n ? first + MSM_AFF_CHK : n);   // exclusive
+    const uint64_t last = (first + chk < n ? first + chk : n);   // exclusive
     const char *pin = (const char *)in;
     char *pout = (char *)out;
     T acc = B::one();
@@ -209,9 +208,12 @@ struct MsmRunner {
     int normalize(const void *d_in, size_t n, void *d_out) {
         if (!n) return LW_OK;
         hipEvent_t pe = c.prof_begin(stream);
-        const uint64_t items = (n + MSM_AFF_CHK - 1) / MSM_AFF_CHK;
+        // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
+        // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
+        const uint32_t chk = n >= ((size_t)1 << 22) ? 128 : 32;
+        const uint64_t items = (n + chk - 1) / chk;
         hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
-                           stream, d_in, (uint64_t)n, d_out);
+                           stream, d_in, (uint64_t)n, chk, d_out);
         c.prof_end("msm_to_affine_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         return LW_OK;

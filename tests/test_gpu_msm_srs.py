@@ -88,11 +88,12 @@ def test_srs_all_points_equal_and_single_bucket():
 
 
 def test_srs_device_resident_large_and_montgomery_scalars():
-    # 2^20 points built on the device from a tiled run; SRS path == projective path on the same inputs
+    # 2^22 points built on the device from a tiled run (the size from which normalisation uses 128-point inversion
+    # runs); SRS path == projective path on the same inputs
     import torch
     from lambda_elliptic_curves_amd import msm
     crv, oid = util.curve_pairs()["bls12_381_g1"]
-    n, base_n = 1 << 20, 1 << 12
+    n, base_n = 1 << 22, 1 << 12
     _, base = util.msm_case(oid, base_n, 77)
     tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n // base_n, 1)
     rng = np.random.default_rng(78)
