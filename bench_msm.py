@@ -140,6 +140,8 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
     dev_c = min(max(L - 4, 4), 16)
     dev_w = (256 + dev_c - 1) // dev_c
     dev_adds = max(n * dev_w - dev_w * ((1 << dev_c) - 1), 0)
+    mixed = L >= 22 and os.environ.get("LW_HIP_MSM_NORMALIZE", "1") != "0"
+    mac_pairs = 2736 if mixed else 3024
     return {
         "metric": "MSM G1 point-adds/sec (BLS12-381, 2^%d points, reference add count adds_ref(N))" % L,
         "value": world * adds_ref(n) * steps / dt, "unit": "point-adds/s",
@@ -153,12 +155,13 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks):
                      "frac": alg_bytes / (dt / steps) / 1e9 / 8000.0, "traffic": None,
                      "kernel": "msm_accumulate_kernel", "avg_launch_ms": (a_launch[1] / a_launch[0]) if a_launch[0] else None,
                      "note": "whole-MSM algorithmic bytes N*(32+144) over the step time; the MSM is integer-VALU bound by ~2 orders of magnitude"},
-        # the bound that applies: complete additions/s of the accumulate kernel against the MAC-pair rate
-        # (3024 MAC pairs per BLS12-381 G1 addition, 17.0 T pairs/s measured: profiles/r01_microbench.txt)
+        # the bound that applies: complete additions/s of the accumulate kernels against the MAC-pair rate (17.0 T
+        # pairs/s measured, profiles/r01_microbench.txt).  From 2^22 points the library normalises the inputs first and
+        # accumulates with the mixed addition (19 N^2 = 2736 MAC pairs); below that the projective one (21 N^2 = 3024).
         "valu": {"accumulate_adds_per_s": dev_adds * steps / (acc_ms * 1e-3) if acc_ms else None,
-                 "peak_adds_per_s": 17.0e12 / 3024, "unit": "complete point additions/s",
-                 "frac": (dev_adds * steps / (acc_ms * 1e-3)) / (17.0e12 / 3024) if acc_ms else None,
-                 "device_adds_per_msm": dev_adds, "device_window_bits": dev_c},
+                 "peak_adds_per_s": 17.0e12 / mac_pairs, "unit": "complete point additions/s",
+                 "frac": (dev_adds * steps / (acc_ms * 1e-3)) / (17.0e12 / mac_pairs) if acc_ms else None,
+                 "device_adds_per_msm": dev_adds, "device_window_bits": dev_c, "mac_pairs_per_addition": mac_pairs},
         "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
         "cpu_baseline": cpu,
     }

@@ -70,6 +70,7 @@ struct Context {
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
     DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
+    DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     lw_timings_t timings = {};
 };

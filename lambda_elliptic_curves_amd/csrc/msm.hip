@@ -367,6 +367,8 @@ int msm_normalize_bn254_g1(Context &c, hipStream_t s, const void *d_in, size_t n
 int msm_normalize_bn254_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 int msm_normalize_bls12381_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 
+int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
+
 // affine_points: d_points are affine pairs produced by msm_normalize_device (2 field elements per row)
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points) {
@@ -378,6 +380,18 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         c.prof_end("msm_scalars_from_mont_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         d_scalars = (const uint64_t *)c.msm_scalars.p;
+    }
+    // Large projective inputs are normalised first (batch inversion, ~5 ms at 2^24) so that the accumulation can use
+    // the mixed addition and 2/3 of the gather bytes (~7.5 ms less at 2^24); below 2^22 the conversion costs more than
+    // it saves.  LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
+    static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
+    if (!affine_points && auto_norm && n >= ((size_t)1 << 22)) {
+        const size_t aff_bytes = n * (lw_hip_curve_point_bytes(curve) / 3) * 2;
+        if (c.msm_affine.ensure(aff_bytes)) return LW_ERR_ALLOC;
+        int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
+        if (rc) return rc;
+        d_points = c.msm_affine.p;
+        affine_points = 1;
     }
     switch (curve) {
         case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host, affine_points);
