@@ -103,7 +103,7 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
 }
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
-// FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks a run of `chk` points, stores the running
+// FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks `chk` points (a strided set, see the kernel), stores the running
 // products of their z in the (not yet final) x slots of the output, inverts the last product once (Fermat), and walks
 // back peeling one inverse per point — 3 products per point plus 1/chk of an inversion instead of a full inversion each.
 // Identity rows (z = 0) are left out of the product and written as (0, 0).
@@ -112,30 +112,35 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
     using B = typename C::B;
     using T = typename B::T;
     constexpr size_t PBY = 3 * B::BYTES, ABY = 2 * B::BYTES;
+    // work-item t owns points t, t + S, t + 2S, ... (S = work-items in the grid): at every step of the walk the lanes
+    // of a wave touch consecutive rows, so the strided runs are read and written coalesced
+    const uint64_t S = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t first = t * chk;
-    if (first >= n) return;
-    const uint64_t last = (first + chk < n ? first + chk : n);   // exclusive
+    if (t >= n) return;
+    uint32_t cnt = 0;
+    while (cnt < chk && t + (uint64_t)cnt * S < n) cnt++;
     const char *pin = (const char *)in;
     char *pout = (char *)out;
     T acc = B::one();
 #pragma nounroll
-    for (uint64_t i = first; i < last; i++) {
+    for (uint32_t j = 0; j < cnt; j++) {
+        const uint64_t i = t + (uint64_t)j * S;
         const T z = B::load(pin + i * PBY + 2 * B::BYTES);
         if (!B::is_zero(z)) acc = B::mul(acc, z);
-        B::store(pout + i * ABY, acc);            // running product through point i
+        B::store(pout + i * ABY, acc);            // running product through this work-item's j-th point
     }
     T inv = B::inv(acc);                          // acc != 0: a product of non-zero field elements (or one)
 #pragma nounroll
-    for (uint64_t i = last; i-- > first;) {
+    for (uint32_t j = cnt; j-- > 0;) {
+        const uint64_t i = t + (uint64_t)j * S;
         const T z = B::load(pin + i * PBY + 2 * B::BYTES);
         if (B::is_zero(z)) {
             aff_store<C>(pout + i * ABY, AffPoint<C>{B::zero(), B::zero()});
             continue;
         }
-        const T prev = i == first ? B::one() : B::load(pout + (i - 1) * ABY);
+        const T prev = j == 0 ? B::one() : B::load(pout + (i - S) * ABY);
         const T zinv = B::mul(inv, prev);         // 1 / z_i
-        inv = B::mul(inv, z);                     // 1 / (running product through point i-1)
+        inv = B::mul(inv, z);                     // 1 / (running product through the previous point)
         const T x = B::load(pin + i * PBY), y = B::load(pin + i * PBY + B::BYTES);
         aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(y, zinv)});
     }
