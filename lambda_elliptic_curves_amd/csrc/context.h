@@ -71,6 +71,8 @@ struct Context {
     DeviceBuf msm_ws;
     DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
     DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
+    hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     lw_timings_t timings = {};
 };

@@ -358,10 +358,14 @@ int msm_waves_per_simd() {
     return w;
 }
 
-int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
-int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
-int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
-int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine);
+int msm_run_bls12381_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine,
+                      hipEvent_t points_ready);
+int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine,
+                      hipEvent_t points_ready);
+int msm_run_bn254_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine,
+                      hipEvent_t points_ready);
+int msm_run_bls12381_g2(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine,
+                      hipEvent_t points_ready);
 int msm_normalize_bls12381_g1(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 int msm_normalize_bn254_g1(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 int msm_normalize_bn254_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
@@ -385,21 +389,40 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     // the mixed addition and 2/3 of the gather bytes (~7.5 ms less at 2^24); below 2^22 the conversion costs more than
     // it saves.  LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
     static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
+    hipEvent_t join = nullptr;
     if (!affine_points && auto_norm && n >= ((size_t)1 << 22)) {
         const size_t aff_bytes = n * (lw_hip_curve_point_bytes(curve) / 3) * 2;
         if (c.msm_affine.ensure(aff_bytes)) return LW_ERR_ALLOC;
-        int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
+        // The normalisation reads only the points and the bucket sort only the scalars; both are latency-bound
+        // (VALUBusy 34 % and < 20 %), so the normalisation runs on a side stream beside the sort and the main stream
+        // joins it just before the first accumulation launch.
+        if (!c.aux_stream) {
+            if (hipStreamCreateWithFlags(&c.aux_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c.aux_join, hipEventDisableTiming) != hipSuccess) {
+                set_error("cannot create the MSM side stream");
+                return LW_ERR_LAUNCH;
+            }
+        }
+        LW_HIP_CHECK(hipEventRecord(c.aux_fork, stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_fork, 0), LW_ERR_LAUNCH);
+        int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, c.aux_stream);
         if (rc) return rc;
+        LW_HIP_CHECK(hipEventRecord(c.aux_join, c.aux_stream), LW_ERR_LAUNCH);
+        join = c.aux_join;
         d_points = c.msm_affine.p;
         affine_points = 1;
     }
+    int rc;
     switch (curve) {
-        case LW_CURVE_BLS12_381_G1: return msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host, affine_points);
-        case LW_CURVE_BN254_G1: return msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host, affine_points);
-        case LW_CURVE_BN254_G2: return msm_run_bn254_g2(c, stream, d_scalars, d_points, n, out_host, affine_points);
-        case LW_CURVE_BLS12_381_G2: return msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host, affine_points);
+        case LW_CURVE_BLS12_381_G1: rc = msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
+        case LW_CURVE_BN254_G1: rc = msm_run_bn254_g1(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
+        case LW_CURVE_BN254_G2: rc = msm_run_bn254_g2(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
+        case LW_CURVE_BLS12_381_G2: rc = msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
         default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
     }
+    if (rc && join) (void)hipStreamSynchronize(c.aux_stream);   // do not leave the side stream running into a failed call's buffers
+    return rc;
 }
 
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream) {

@@ -208,6 +208,7 @@ struct MsmRunner {
     hipStream_t stream;
     uint32_t W;
     bool affine = false;   // d_points are affine pairs (pre-normalised SRS)
+    hipEvent_t points_ready = nullptr;   // recorded on a side stream once d_points is complete; joined before the first accumulation
 
     // SRS preparation (lw_hip_srs_create*): n projective rows -> n affine pairs
     int normalize(const void *d_in, size_t n, void *d_out) {
@@ -284,6 +285,7 @@ struct MsmRunner {
                             maxlen_d, scan_tmp, stream);
             LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+            if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
         }
         // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
         const uint32_t *seg = off;
