@@ -247,6 +247,10 @@ void lw_hip_shutdown(void) {
     }
     c.msm_ws.release();
     c.msm_scalars.release();
+    c.msm_affine.release();
+    if (c.aux_stream) { (void)hipStreamDestroy(c.aux_stream); c.aux_stream = nullptr; }
+    if (c.aux_fork) { (void)hipEventDestroy(c.aux_fork); c.aux_fork = nullptr; }
+    if (c.aux_join) { (void)hipEventDestroy(c.aux_join); c.aux_join = nullptr; }
     c.host_io_a.release();
     c.host_io_b.release();
     c.initialised = false;
