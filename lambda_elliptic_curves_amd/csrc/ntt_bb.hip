@@ -33,7 +33,7 @@ struct BbPassParams {
     uint32_t nsteps;
     uint32_t k[8];
     uint32_t scale, sc;        // N^-1 (R = 2^32 domain) on the last pass of an inverse transform
-    uint32_t dbg;              // diagnostics (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip loads, bit2 skip stores
+    uint32_t dbg;              // diagnostics (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip loads, bit2 skip stores, bit3 old last-pass mapping
 };
 
 __device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -57,8 +57,13 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
     const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
     const uint32_t logCh = logC - lgV;               // columns proper (distinct tiles in the last pass)
     const uint32_t sh = r - t0 - K;
+    // Last pass: work-items walk rows fastest in every step.  In its first step that matches the memory order of the
+    // input (column, row, component); in the later ones it keeps the lanes of a wave inside a few columns, whose
+    // twiddles T[(hi_c << t) | x] are then neighbours in the table (columns-fastest made every lane fetch a different
+    // cache line).  LDS slots are XOR-swizzled by row bits (lds_slot) so rows-fastest accesses spread over the banks.
+    const bool rows_fastest = LAST && (step == 0 || !(p.dbg & 8));
     uint32_t c, mr;
-    if (LAST && step == 0) {   // memory order of the last pass's input is (column, row, component)
+    if (rows_fastest) {
         const uint32_t comp = w & ((1u << lgV) - 1);
         mr = (w >> lgV) & ((1u << (r - K)) - 1);
         c = ((w >> (lgV + r - K)) << lgV) | comp;
@@ -66,6 +71,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
         c = w & ((1u << logC) - 1);
         mr = w >> logC;
     }
+    const uint32_t swz = (LAST && !(p.dbg & 8)) ? ((1u << logC) - 1) : 0u;
     const uint32_t m_low = mr & ((1u << sh) - 1);
     const uint32_t m_high = mr >> sh;
     const uint32_t mbase = (m_high << (sh + K)) | m_low;
@@ -83,7 +89,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             else g = base + (m << lgS) + c;
             x[j] = (p.dbg & 2) ? g : bb_load_word<W64>(gin, g);
         } else {
-            x[j] = lds[(m << logC) | c];
+            x[j] = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
         }
     }
     if (!(p.dbg & 1))
@@ -112,7 +118,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const uint32_t m = mbase | ((uint32_t)j << sh);
-        lds[(m << logC) | c] = x[j];
+        lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))] = x[j];
     }
 }
 
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         uint32_t g;
         if (!LAST) g = base + (m << lgS) + c;
         else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
-        if (!(p.dbg & 4)) bb_store_word<W64>(gout, g, lds[e]);
+        const uint32_t swz = (LAST && !(p.dbg & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
+        if (!(p.dbg & 4)) bb_store_word<W64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
     }
 }
 
