@@ -143,7 +143,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
 // pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen.
 // Both sweeps over the bin issue FINE_UNROLL independent loads per work-item before touching LDS: the kernel is bound
 // by memory latency (VALUBusy 2 %), not by the LDS atomics.
-constexpr int FINE_UNROLL = 4;
+constexpr int FINE_UNROLL = 8;
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, uint32_t fine_bits,
                                                                uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen) {
