@@ -96,9 +96,14 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
     const uint64_t p1 = min(n, p0 + ppb);
     // zero digits go to a dummy slot so that the LDS atomics of a scalar's windows are issued back to back
     // (no branch between them); four windows are in flight before any result is consumed
+    // the next scalar is fetched while the current one is binned (the loop is latency-bound)
+    uint32_t sn[8];
+    if (p0 + tid < p1) load_scalar_words(scalars, p0 + tid, sn);
     for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
         uint32_t s[8];
-        load_scalar_words(scalars, i, s);
+#pragma unroll
+        for (int q = 0; q < 8; q++) s[q] = sn[q];
+        if (i + SORT_THREADS < p1) load_scalar_words(scalars, i + SORT_THREADS, sn);
         for (uint32_t w0 = 0; w0 < W; w0 += 4) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
@@ -120,9 +125,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
         h[b] = 0;
     }
     __syncthreads();
+    if (p0 + tid < p1) load_scalar_words(scalars, p0 + tid, sn);
     for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
         uint32_t s[8];
-        load_scalar_words(scalars, i, s);
+#pragma unroll
+        for (int q = 0; q < 8; q++) s[q] = sn[q];
+        if (i + SORT_THREADS < p1) load_scalar_words(scalars, i + SORT_THREADS, sn);
         for (uint32_t w0 = 0; w0 < W; w0 += 4) {
             uint32_t d[4], b[4], r[4];
 #pragma unroll
