@@ -173,3 +173,30 @@ def test_msm_above_2_24_points_splits_additively():
     # and the small tail agrees with the oracle's Pippenger outright
     want = O.msm(oid, sc[n_lo:], np.ascontiguousarray(np.tile(base, (n // base_n, 1))[n_lo:]))
     assert aff(oid, hi) == aff(oid, want)
+
+
+def test_msm_large_input_with_identity_rows():
+    # From 2^22 points the library normalises the inputs (batch inversion over strided runs of 128) before the
+    # accumulation; identity rows (z = 0) must drop out of every run.  Replacing them by any other point with a zero
+    # scalar gives the same sum.
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bn254_g1"]
+    n, base_n = 1 << 22, 1 << 12
+    _, base = util.msm_case(oid, base_n, 31)
+    rng = np.random.default_rng(32)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    pts = np.tile(base, (n // base_n, 1))
+    hole = rng.random(n) < 0.2
+    hole[[0, 1, n - 1]] = True
+    with_id = pts.copy()
+    with_id[hole] = O.ec_neutral(oid)
+    sc_zeroed = sc.copy()
+    sc_zeroed[hole] = 0
+    got = msm.msm_device(crv, torch.from_numpy(sc.view(np.int64)).cuda(), torch.from_numpy(with_id.view(np.int64)).cuda(), n)
+    ref = msm.msm_device(crv, torch.from_numpy(sc_zeroed.view(np.int64)).cuda(), torch.from_numpy(pts.view(np.int64)).cuda(), n)
+    assert aff(oid, got) == aff(oid, ref)
+    # anchor the pair to the oracle on a slice small enough for the CPU
+    m = 1 << 12
+    small = msm.msm(crv, sc[:m], with_id[:m])
+    assert aff(oid, small) == aff(oid, O.msm(oid, sc[:m], with_id[:m]))
