@@ -43,6 +43,23 @@ struct FpOps {
     LW_HD static T sqr(const T &a) { return mul(a, a); }
     LW_HD static T neg(const T &a) { return fe_neg<F>(a); }
     LW_HD static T dbl(const T &a) { return fe_add<F>(a, a); }
+    // value held by the neighbouring lane (lanes 2i <-> 2i+1), one DPP move per limb; device code only
+    LW_HD static T lane_swap(const T &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        T r;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xF, 0xF, true);
+        return r;
+#else
+        return a;
+#endif
+    }
+    LW_HD static T select(bool c, const T &a, const T &b) {
+        T r;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) r.v[i] = c ? a.v[i] : b.v[i];
+        return r;
+    }
     LW_HD static T zero() { return T::zero(); }
     LW_HD static T one() { return T::one(); }
     LW_HD static bool is_zero(const T &a) { return a.is_zero(); }
@@ -107,6 +124,8 @@ struct Fp2Ops {
     }
     LW_HD static T neg(const T &a) { return T{fe_neg<F>(a.c0), fe_neg<F>(a.c1)}; }
     LW_HD static T dbl(const T &a) { return add(a, a); }
+    LW_HD static T lane_swap(const T &a) { return T{FpOps<F>::lane_swap(a.c0), FpOps<F>::lane_swap(a.c1)}; }
+    LW_HD static T select(bool c, const T &a, const T &b) { return T{FpOps<F>::select(c, a.c0, b.c0), FpOps<F>::select(c, a.c1, b.c1)}; }
     LW_HD static T zero() { return T{Fe<F>::zero(), Fe<F>::zero()}; }
     LW_HD static T one() { return T{Fe<F>::one(), Fe<F>::zero()}; }
     LW_HD static bool is_zero(const T &a) { return a.c0.is_zero() && a.c1.is_zero(); }

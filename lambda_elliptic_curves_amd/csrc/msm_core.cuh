@@ -154,19 +154,29 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
 template <class C>
 __global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const void *in, uint32_t n, uint32_t g,
                                                                      uint32_t ngroups, uint32_t nwin, void *out) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= ngroups) return;
+    // A level costs the latency of its chain of dependent additions (the kernel runs at about one wave per SIMD).  The
+    // two additions of a step, q += running and running += in[d], both read the old `running`, so a pair of lanes does
+    // them side by side: the even lane keeps `running`, the odd lane keeps `q` and receives the even lane's value by
+    // DPP before each step.  The chain is g additions long instead of 2g.
+    using B = typename C::B;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = t >> 1;
+    const bool is_q = t & 1;
+    if (j >= ngroups) return;          // pairs are never split: 2j and 2j+1 leave together
     const uint32_t w = blockIdx.y;
     const size_t base = (size_t)w * n;
     const uint32_t d0 = j * g, d1 = min(n, d0 + g);
-    Point<C> running = pt_identity<C>(), q = pt_identity<C>();
+    Point<C> acc = pt_identity<C>();
 #pragma nounroll
     for (uint32_t d = d1; d-- > d0;) {
-        q = pt_add<C>(q, running);
-        running = pt_add<C>(running, pt_ld<C>(in, base + d));
+        const Point<C> x = pt_ld<C>(in, base + d);
+        Point<C> operand;
+        operand.x = B::select(is_q, B::lane_swap(acc.x), x.x);
+        operand.y = B::select(is_q, B::lane_swap(acc.y), x.y);
+        operand.z = B::select(is_q, B::lane_swap(acc.z), x.z);
+        acc = pt_add<C>(acc, operand);
     }
-    pt_st<C>(out, (size_t)w * ngroups + j, running);
-    pt_st<C>(out, (size_t)(nwin + w) * ngroups + j, q);
+    pt_st<C>(out, (size_t)(is_q ? nwin + w : w) * ngroups + j, acc);
 }
 
 // Level results (one point per array, rows as above) -> S[w] = sumQ[w] + 2^k * S(A)[w],  A[w] = sumA[w]
@@ -245,8 +255,8 @@ struct MsmRunner {
         char *lvl = (char *)cv.take(PB * 2 * (size_t)nwin * ng);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((ng + MSM_THREADS - 1) / MSM_THREADS, nwin), dim3(MSM_THREADS), 0,
-                               stream, (const void *)in, n, g, ng, nwin, (void *)lvl);
+            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((2 * ng + MSM_THREADS - 1) / MSM_THREADS, nwin), dim3(MSM_THREADS), 0,
+                               stream, (const void *)in, n, g, ng, nwin, (void *)lvl);   // two lanes per group
             c.prof_end("msm_group_sum_kernel", pe, stream);
         }
         char *S2, *A2;
