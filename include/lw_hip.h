@@ -75,7 +75,7 @@ typedef enum {
     LW_ERR_NO_DEVICE = -5,       /* CudaError::DeviceNotFound */
     LW_ERR_ALLOC = -6,           /* CudaError::AllocateMemory */
     LW_ERR_LAUNCH = -7,          /* CudaError::Launch / FunctionError */
-    LW_ERR_COMM = -8,
+    LW_ERR_COMM = -8,            /* RCCL unavailable / no communicator / collective failed (multi-GPU entry points) */
     LW_ERR_BAD_ARG = -9,
     LW_ERR_INV_ZERO = -10        /* FieldError::InvZeroError (zero coset offset) */
 } lw_status_t;
@@ -98,11 +98,23 @@ typedef struct {
 } lw_kernel_time_t;
 typedef struct {
     int n;
-    lw_kernel_time_t k[16];
+    lw_kernel_time_t k[32];
 } lw_profile_t;
 
 /* ---- context ---- */
-int lw_hip_init(const int *device_ids, int n_devices); /* NULL,0 -> current device */
+/* One context per process, bound to ONE device: NULL,0 -> the calling thread's current device; n_devices > 1 ->
+ * LW_ERR_BAD_ARG (multi-GPU jobs run one process per GPU and shard through lw_hip_comm_init below).  Calling it again
+ * with another device id releases every cached table / workspace of the old device first; destroy lw_srs_t handles
+ * before doing that.  Every entry point binds the context's device for the calling thread for the duration of the call
+ * (the HIP current device is per thread) and restores the caller's afterwards.
+ *
+ * Stream contract of the *_device entry points: work is enqueued on `hip_stream` and the call returns without waiting
+ * for it, except where a result is handed back through a host pointer (the MSM's out_point_host, out_root): those
+ * synchronise the stream before returning.  The library's scratch, tables and workspaces are shared by all calls; a
+ * call on a different stream than the previous one first waits (hipStreamWaitEvent) for the previous call's work, so
+ * calls may be issued from any stream or thread in any order.  Host-side the calls are serialised by one lock
+ * (callers that want column parallelism pass `batch`, not threads). */
+int lw_hip_init(const int *device_ids, int n_devices);
 void lw_hip_shutdown(void);
 int lw_hip_device_count(void);
 const char *lw_hip_last_error(void);
@@ -151,6 +163,41 @@ int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *
 int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                             uint32_t log2n_total, uint32_t log2_shards, uint64_t j2_begin, uint64_t slice_len,
                             uint64_t chunk_stride_elems, uint32_t batch, uint64_t batch_stride_elems, void *hip_stream);
+
+/* ---- Multi-GPU: one process per GPU, library-owned RCCL communicator over xGMI (no reference counterpart: the
+ * reference has no multi-device path).  Rank 0 calls lw_hip_comm_unique_id and hands the 128 bytes to the other
+ * processes out of band (exactly ncclGetUniqueId's contract); every process then calls lw_hip_comm_init (collective)
+ * after lw_hip_init(&device, 1).  The communicator lives in the library context and is released by
+ * lw_hip_comm_shutdown / lw_hip_shutdown.  nranks in {1, 2, 4, 8}.  Every failure of this path (RCCL not loadable,
+ * no communicator, a failing collective) is LW_ERR_COMM. */
+#define LW_HIP_COMM_ID_BYTES 128
+int lw_hip_comm_unique_id(uint8_t *out_id /* LW_HIP_COMM_ID_BYTES */);
+int lw_hip_comm_init(const uint8_t *unique_id, int rank, int nranks);
+int lw_hip_comm_shutdown(void);
+int lw_hip_comm_info(int *rank, int *nranks);
+
+/* One transform of 2^log2n_total elements (or `batch` of them) block-distributed over the communicator's G ranks: this
+ * rank holds elements [rank*M, (rank+1)*M) of the natural-order vector, M = 2^log2n_total / G; batch entries are M
+ * elements apart (dense).  Collective: every rank calls it with the same arguments.  natural_output != 0: d_out_local
+ * receives this rank's block of the natural-order result, i.e. the concatenation over ranks is byte-identical to
+ * lw_hip_ntt_device on the concatenated input (Polynomial::evaluate_fft / interpolate_fft semantics);
+ * natural_output == 0: the cyclic shard X[rank + G*k], k = 0..M-1 (one all-to-all fewer).  d_out_local may alias
+ * d_in_local.  Schedule: all-to-all, cross-shard step (lw_hip_ntt_cross_device), all-to-all, local M-point NTT
+ * [, all-to-all, interleave] — see csrc/comm.hip. */
+int lw_hip_ntt_sharded_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_local, void *d_out_local,
+                              uint32_t log2n_total, uint32_t batch, int natural_output, void *hip_stream);
+/* The same schedule with G = 2^log2_shards virtual ranks walked on ONE device (exchanges are device-to-device
+ * copies): d_in_full / d_out_full hold the whole vectors (batch entries 2^log2n_total apart), virtual rank g owning
+ * block g.  With natural_output == 0 block g of d_out_full receives X[g + G*k].  Used to parity-test the exchange
+ * schedule on a one-GPU box; needs no communicator. */
+int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                                       uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output,
+                                       void *hip_stream);
+/* msm over points sharded across the ranks: every rank passes its n_local (scalar, point) pairs (n_local may differ
+ * per rank, 0 allowed); each runs the full Pippenger on its shard, the G partial sums are all-gathered (one point
+ * each) and added.  Every rank receives the sum over all ranks' pairs, normalised like lw_hip_msm. */
+int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n_local,
+                              void *out_point_host, void *hip_stream);
 
 /* ---- Polynomial FFT API (host buffers, reference semantics) ----
  * evaluate: len = max(coeff_len, domain_size).next_power_of_two() * blowup_factor where coeff_len is

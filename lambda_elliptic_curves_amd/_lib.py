@@ -27,6 +27,8 @@ EXPORTS = [
     "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
     "lw_hip_srs_create", "lw_hip_srs_create_device", "lw_hip_srs_destroy", "lw_hip_msm_srs", "lw_hip_msm_srs_device",
     "lw_hip_msm_srs_fr",
+    "lw_hip_comm_unique_id", "lw_hip_comm_init", "lw_hip_comm_shutdown", "lw_hip_comm_info",
+    "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_msm_sharded_device",
 ]
 
 
@@ -40,7 +42,7 @@ class KernelTime(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("n", C.c_int), ("k", KernelTime * 16)]
+    _fields_ = [("n", C.c_int), ("k", KernelTime * 32)]
 
 
 _lib = None
@@ -121,6 +123,19 @@ def lib():
     L.lw_hip_msm_srs_fr.restype = i
     L.lw_hip_msm_srs_device.argtypes = [vp, vp, sz, vp, vp]
     L.lw_hip_msm_srs_device.restype = i
+    L.lw_hip_comm_unique_id.argtypes = [vp]
+    L.lw_hip_comm_unique_id.restype = i
+    L.lw_hip_comm_init.argtypes = [vp, i, i]
+    L.lw_hip_comm_init.restype = i
+    L.lw_hip_comm_shutdown.restype = i
+    L.lw_hip_comm_info.argtypes = [C.POINTER(i), C.POINTER(i)]
+    L.lw_hip_comm_info.restype = i
+    L.lw_hip_ntt_sharded_device.argtypes = [i, i, i, vp, vp, u32, u32, i, vp]
+    L.lw_hip_ntt_sharded_device.restype = i
+    L.lw_hip_ntt_sharded_selftest_device.argtypes = [i, i, i, vp, vp, u32, u32, u32, i, vp]
+    L.lw_hip_ntt_sharded_selftest_device.restype = i
+    L.lw_hip_msm_sharded_device.argtypes = [i, vp, vp, sz, vp, vp]
+    L.lw_hip_msm_sharded_device.restype = i
     _lib = L
     return L
 

@@ -71,7 +71,9 @@ void ntt_set_max_pass_stages(uint32_t r);
 void ntt_set_debug(uint32_t d);
 
 static int init_locked(Context &c, const int *device_ids, int n_devices) {
-    if (const char *e = getenv("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));
+#ifdef LW_HIP_ABLATION
+    if (const char *e = getenv("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));   // wrong results, timing only
+#endif
     if (const char *e = getenv("LW_HIP_NTT_MAX_R")) ntt_set_max_pass_stages((uint32_t)atoi(e));
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -81,6 +83,10 @@ static int init_locked(Context &c, const int *device_ids, int n_devices) {
         return LW_ERR_NO_DEVICE;
     }
     int dev = 0;
+    if (device_ids && n_devices > 1) {   // one process (context) per GPU; multi-GPU jobs use lw_hip_comm_init
+        set_error("lw_hip_init takes one device id per process (got %d); shard across processes with lw_hip_comm_init", n_devices);
+        return LW_ERR_BAD_ARG;
+    }
     if (device_ids && n_devices > 0) {
         dev = device_ids[0];
         if (dev < 0 || dev >= count) {
@@ -97,9 +103,77 @@ static int init_locked(Context &c, const int *device_ids, int n_devices) {
         set_error("device %d is %s; this library ships gfx950 code objects only", dev, prop.gcnArchName);
         return LW_ERR_NO_DEVICE;
     }
+    if (c.initialised && c.device != dev) {   // every cached table / workspace lives on the old device
+        (void)hipSetDevice(c.device);
+        c.release_all();
+        (void)hipSetDevice(dev);
+    }
     c.device = dev;
     c.initialised = true;
     return LW_OK;
+}
+
+void comm_release(Context &c);   // comm.hip
+
+void Context::release_all() {
+    (void)hipDeviceSynchronize();
+    comm_release(*this);
+    for (int f = 0; f < 3; f++)
+        for (int d = 0; d < 2; d++) {
+            tw[f][d].buf.release();
+            tw[f][d].valid = false;
+        }
+    scratch.release();
+    small.release();
+    for (int i = 0; i < 3; i++) {
+        coset[i].lo.release();
+        coset[i].hi.release();
+        coset[i].valid = false;
+    }
+    msm_ws.release();
+    msm_scalars.release();
+    msm_affine.release();
+    shard_a.release();
+    shard_b.release();
+    if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }
+    if (aux_fork) { (void)hipEventDestroy(aux_fork); aux_fork = nullptr; }
+    if (aux_join) { (void)hipEventDestroy(aux_join); aux_join = nullptr; }
+    if (order_event) { (void)hipEventDestroy(order_event); order_event = nullptr; }
+    have_last = false;
+    for (auto &sp : spans) { (void)hipEventDestroy(sp.e0); (void)hipEventDestroy(sp.e1); }
+    spans.clear();
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    event_pool.clear();
+    profiling = false;
+    host_io_a.release();
+    host_io_b.release();
+    timings.twiddle_bytes = timings.scratch_bytes = 0;
+}
+
+Entry::Entry(void *hip_stream) : c(ctx()), lock(c.mu), stream((hipStream_t)hip_stream) {
+    rc = ensure_init();
+    if (rc) return;
+    if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
+    if (prev_device != c.device && hipSetDevice(c.device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", c.device);
+        rc = LW_ERR_NO_DEVICE;
+        return;
+    }
+    if (c.have_last && c.last_stream != stream && c.order_event &&
+        hipStreamWaitEvent(stream, c.order_event, 0) != hipSuccess) {
+        set_error("hipStreamWaitEvent on the previous call's stream failed");
+        rc = LW_ERR_LAUNCH;
+    }
+}
+Entry::~Entry() {
+    if (rc == LW_OK || c.initialised) {
+        if (!c.order_event && c.initialised) (void)hipEventCreateWithFlags(&c.order_event, hipEventDisableTiming);
+        if (c.order_event && hipEventRecord(c.order_event, stream) == hipSuccess) {
+            c.last_stream = stream;
+            c.have_last = true;
+        }
+    }
+    if (prev_device >= 0 && prev_device != c.device) (void)hipSetDevice(prev_device);
 }
 
 int ensure_init() {
@@ -133,7 +207,7 @@ int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d
 int gen_twiddles_device(Context &c, lw_field_t field, lw_layout_t layout, uint32_t order, int config, void *d_out, hipStream_t stream);
 int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream);
 
-static uint32_t two_adicity(lw_field_t f) {
+uint32_t field_two_adicity(lw_field_t f) {
     switch (f) {
         case LW_FIELD_STARK252: return Stark252::TWO_ADICITY;
         case LW_FIELD_BLS12_381_FR: return Fr381::TWO_ADICITY;
@@ -141,7 +215,7 @@ static uint32_t two_adicity(lw_field_t f) {
     }
 }
 
-static int check_field_layout(lw_field_t field, lw_layout_t layout) {
+int check_field_layout(lw_field_t field, lw_layout_t layout) {
     bool ok = false;
     if (field == LW_FIELD_STARK252 || field == LW_FIELD_BLS12_381_FR) ok = layout == LW_LAYOUT_U64_LIMBS_MS_FIRST;
     if (field == LW_FIELD_BABYBEAR)
@@ -172,7 +246,7 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
         set_error("order %u > 63", log2n);
         return LW_ERR_ORDER_TOO_LARGE;
     }
-    if (log2n > two_adicity(field)) {   // traits.rs:88-90
+    if (log2n > field_two_adicity(field)) {   // traits.rs:88-90
         set_error("no primitive 2^%u-th root of unity in this field", log2n);
         return LW_ERR_ROOT_OF_UNITY;
     }
@@ -232,27 +306,11 @@ void lw_hip_shutdown(void) {
     Context &c = ctx();
     std::lock_guard<std::mutex> g(c.mu);
     if (!c.initialised) return;
-    (void)hipDeviceSynchronize();
-    for (int f = 0; f < 3; f++)
-        for (int d = 0; d < 2; d++) {
-            c.tw[f][d].buf.release();
-            c.tw[f][d].valid = false;
-        }
-    c.scratch.release();
-    c.small.release();
-    for (int i = 0; i < 3; i++) {
-        c.coset[i].lo.release();
-        c.coset[i].hi.release();
-        c.coset[i].valid = false;
-    }
-    c.msm_ws.release();
-    c.msm_scalars.release();
-    c.msm_affine.release();
-    if (c.aux_stream) { (void)hipStreamDestroy(c.aux_stream); c.aux_stream = nullptr; }
-    if (c.aux_fork) { (void)hipEventDestroy(c.aux_fork); c.aux_fork = nullptr; }
-    if (c.aux_join) { (void)hipEventDestroy(c.aux_join); c.aux_join = nullptr; }
-    c.host_io_a.release();
-    c.host_io_b.release();
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(c.device);
+    c.release_all();
+    if (prev >= 0) (void)hipSetDevice(prev);
     c.initialised = false;
 }
 
@@ -265,10 +323,14 @@ int lw_hip_device_count(void) {
 const char *lw_hip_last_error(void) { return g_last_error.c_str(); }
 
 int lw_hip_profile_begin(void) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
+    for (auto &sp : c.spans) {   // a begin without an end: recycle the pending events
+        c.event_pool.push_back(sp.e0);
+        c.event_pool.push_back(sp.e1);
+    }
     c.spans.clear();
     c.profiling = true;
     return LW_OK;
@@ -276,8 +338,9 @@ int lw_hip_profile_begin(void) {
 
 int lw_hip_profile_end(lw_profile_t *out) {
     if (!out) return LW_ERR_BAD_ARG;
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
     c.profiling = false;
     memset(out, 0, sizeof(*out));
     LW_HIP_CHECK(hipDeviceSynchronize(), LW_ERR_LAUNCH);
@@ -287,7 +350,7 @@ int lw_hip_profile_end(lw_profile_t *out) {
         int idx = -1;
         for (int i = 0; i < out->n; i++)
             if (strcmp(out->k[i].name, sp.name) == 0) idx = i;
-        if (idx < 0 && out->n < 16) {
+        if (idx < 0 && out->n < (int)(sizeof(out->k) / sizeof(out->k[0]))) {
             idx = out->n++;
             strncpy(out->k[idx].name, sp.name, sizeof(out->k[idx].name) - 1);
         }
@@ -332,10 +395,10 @@ size_t lw_hip_curve_point_bytes(lw_curve_t curve) {
 
 int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
                       uint32_t batch, size_t batch_stride_elems, const void *coset_offset_or_null, void *hip_stream) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     auto t0 = std::chrono::steady_clock::now();
     rc = ntt_device_locked(c, field, layout, dir, d_in, d_out, log2n, batch, batch_stride_elems, coset_offset_or_null,
                            (hipStream_t)hip_stream);
@@ -350,14 +413,13 @@ int lw_hip_gen_twiddles(lw_field_t field, lw_layout_t layout, uint64_t order, in
     if (rc) return rc;
     if (order > 63) { set_error("Order should be less than or equal to 63, but is %llu", (unsigned long long)order); return LW_ERR_ORDER_TOO_LARGE; }
     if (config < 0 || config > 3) { set_error("bad roots config %d", config); return LW_ERR_BAD_ARG; }
-    if (order > two_adicity(field)) { set_error("no primitive 2^%llu-th root of unity in this field", (unsigned long long)order); return LW_ERR_ROOT_OF_UNITY; }
+    if (order > field_two_adicity(field)) { set_error("no primitive 2^%llu-th root of unity in this field", (unsigned long long)order); return LW_ERR_ROOT_OF_UNITY; }
     const uint64_t count = (1ull << order) / 2;
     if (count == 0) return LW_OK;
     if (!out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
     // twiddles live in the domain field: one base word per entry for every BabyBear shape
     const size_t eb = field == LW_FIELD_BABYBEAR ? (layout == LW_LAYOUT_BABYBEAR_U32_R32 ? 4 : 8) : 32;
     if (c.host_io_b.ensure(count * eb)) return LW_ERR_ALLOC;
@@ -377,10 +439,9 @@ int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *
     uint32_t log2n = 0;
     while (((size_t)1 << log2n) < n) log2n++;
     if (log2n > 32) { set_error("2^%u elements exceed device memory", log2n); return LW_ERR_ALLOC; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
     const size_t eb = lw_hip_field_elem_bytes(field, layout);
     if (c.host_io_a.ensure(n * eb) || c.host_io_b.ensure(n * eb)) return LW_ERR_ALLOC;
     LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, in, n * eb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
@@ -393,14 +454,14 @@ int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *
 int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                             uint32_t log2n_total, uint32_t log2_shards, uint64_t j2_begin, uint64_t slice_len,
                             uint64_t chunk_stride_elems, uint32_t batch, uint64_t batch_stride_elems, void *hip_stream) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     rc = check_field_layout(field, layout);
     if (rc) return rc;
     if (log2n_total > 63) { set_error("order %u > 63", log2n_total); return LW_ERR_ORDER_TOO_LARGE; }
-    if (log2n_total > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n_total); return LW_ERR_ROOT_OF_UNITY; }
+    if (log2n_total > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n_total); return LW_ERR_ROOT_OF_UNITY; }
     if (!d_in || !d_out || d_in == d_out) { set_error("cross step needs distinct non-null buffers"); return LW_ERR_BAD_ARG; }
     if (batch == 0 || slice_len == 0) return LW_OK;
     return ntt_cross_device(c, field, layout, dir, d_in, d_out, log2n_total, log2_shards, j2_begin, slice_len, chunk_stride_elems,
@@ -409,10 +470,10 @@ int lw_hip_ntt_cross_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, 
 
 int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_coeffs, uint32_t log2_coeffs, void *d_out,
                           uint32_t log2n, uint32_t batch, const void *coset_offset_or_null, void *hip_stream) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     if (log2_coeffs > log2n) { set_error("2^%u coefficients do not fit a 2^%u domain", log2_coeffs, log2n); return LW_ERR_BAD_ARG; }
     auto t0 = std::chrono::steady_clock::now();
     rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, d_coeffs, d_out, log2n, batch, 0, coset_offset_or_null,
@@ -424,14 +485,14 @@ int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_co
 
 int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t log2n, uint32_t batch,
                size_t batch_stride_elems, const void *coset_offset_or_null) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     rc = check_field_layout(field, layout);
     if (rc) return rc;
     if (log2n > 63) { set_error("order %u > 63", log2n); return LW_ERR_ORDER_TOO_LARGE; }
-    if (log2n > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
+    if (log2n > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
     if (batch == 0) return LW_OK;
     if (!in || !out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
     auto t0 = std::chrono::steady_clock::now();
@@ -489,12 +550,11 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
     }
     uint32_t log2n = 0;
     while (((size_t)1 << log2n) < len) log2n++;
-    if (log2n > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
+    if (log2n > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", log2n); return LW_ERR_ROOT_OF_UNITY; }
 
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
     auto t0 = std::chrono::steady_clock::now();
     // Zero padding happens after scaling in the reference, so padded slots stay zero either way.  For the 256-bit
     // fields only the power-of-two block that holds the coefficients is uploaded; the transform extends it (LDE path).
@@ -541,10 +601,10 @@ int lw_polynomial_interpolate_fft(lw_field_t field, lw_layout_t layout, const vo
 
 static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_point_host,
                             void *hip_stream, int mont) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     if (lw_hip_curve_point_bytes(curve) == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
     auto t0 = std::chrono::steady_clock::now();
     rc = msm_device(c, curve, d_scalars, d_points, n, out_point_host, (hipStream_t)hip_stream, mont, 0);
@@ -558,10 +618,10 @@ int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint
     if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("Merkle commitment supports the 256-bit fields"); return LW_ERR_BAD_ARG; }
     if (!d_columns || !d_nodes || n_cols == 0) { set_error("null buffer or no columns"); return LW_ERR_BAD_ARG; }
     if (log2n > 31) { set_error("2^%u leaves", log2n); return LW_ERR_ALLOC; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     if (col_stride_elems == 0) col_stride_elems = 1ull << log2n;
     rc = merkle_commit_device(c, d_columns, n_cols, col_stride_elems, log2n, bit_reverse, d_nodes, (hipStream_t)hip_stream);
     if (rc) return rc;
@@ -579,10 +639,10 @@ int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_co
     if (log2n > 31) { set_error("2^%u leaves", log2n); return LW_ERR_ALLOC; }
     const size_t n = (size_t)1 << log2n;
     {
-        Context &c = ctx();
-        std::lock_guard<std::mutex> g(c.mu);
-        int rc = ensure_init();
-        if (rc) return rc;
+        Entry en(nullptr);
+        if (en.rc) return en.rc;
+        Context &c = en.c;
+        int rc = LW_OK;
         if (c.host_io_a.ensure((size_t)n_cols * n * 32) || c.host_io_b.ensure((2 * n - 1) * 32)) return LW_ERR_ALLOC;
         LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, columns, (size_t)n_cols * n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
         rc = merkle_commit_device(c, c.host_io_a.p, n_cols, n, log2n, bit_reverse, c.host_io_b.p, 0);
@@ -608,11 +668,11 @@ int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, co
     while (((size_t)1 << lgd) < domain_size) lgd++;
     while (((size_t)1 << lgb) < n_out) lgb++;
     if (lgb > lgd) lgb = lgd;
-    if (lgd > two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", lgd); return LW_ERR_ROOT_OF_UNITY; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    if (lgd > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", lgd); return LW_ERR_ROOT_OF_UNITY; }
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     const size_t blk = (size_t)1 << lgb;
     // a: [coeffs | zeta words | folded block]   b: [eval | eval_br | nodes]
     const size_t a_coeffs = n_coeffs * 32, a_zeta = 256, a_poly = blk * 32;
@@ -651,10 +711,10 @@ int lw_groth16_h_coefficients(const void *l_coeffs, const void *r_coeffs, const 
     uint32_t lg = 0;
     while (((size_t)1 << lg) < num_gates) lg++;
     if (lg + 1 > Fr381::TWO_ADICITY) { set_error("no primitive 2^%u-th root of unity in this field", lg + 1); return LW_ERR_ROOT_OF_UNITY; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     const size_t n = 2 * num_gates;
     const size_t blk = num_gates < 2 ? 2 : num_gates;   // coefficient block per polynomial on the device (zero padded)
     // device staging: [l | r | o] coefficient blocks, then 3 evaluation vectors + output
@@ -694,10 +754,10 @@ static int msm_host_entry(lw_curve_t curve, const uint64_t *scalars, size_t n_sc
         set_error("scalars and points have different lengths: %zu vs %zu", n_scalars, n_points);
         return LW_ERR_LENGTH_MISMATCH;
     }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     auto t0 = std::chrono::steady_clock::now();
     const size_t n = n_points;
     if (n) {
@@ -742,19 +802,19 @@ static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream
 }
 int lw_hip_srs_create_device(lw_curve_t curve, const void *d_points, size_t n_points, void *hip_stream, lw_srs_t **out_srs) {
     if (!out_srs || lw_hip_curve_point_bytes(curve) == 0 || (n_points && !d_points)) { set_error("bad curve or null argument"); return LW_ERR_BAD_ARG; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     return srs_build(curve, d_points, n_points, (hipStream_t)hip_stream, out_srs);
 }
 int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_srs_t **out_srs) {
     const size_t pb = lw_hip_curve_point_bytes(curve);
     if (!out_srs || pb == 0 || (n_points && !points)) { set_error("bad curve or null argument"); return LW_ERR_BAD_ARG; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     if (n_points) {
         if (c.host_io_b.ensure(n_points * pb)) return LW_ERR_ALLOC;
         LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n_points * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
@@ -763,8 +823,7 @@ int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_
 }
 int lw_hip_srs_destroy(lw_srs_t *srs) {
     if (!srs) return LW_OK;
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    Entry en(nullptr);   // binds the context's device for the hipFree
     srs->pts.release();
     delete srs;
     return LW_OK;
@@ -777,10 +836,10 @@ static int msm_srs_entry(const lw_srs_t *srs, const uint64_t *scalars, size_t n,
         return LW_ERR_LENGTH_MISMATCH;
     }
     if (n && !scalars) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    int rc = ensure_init();
-    if (rc) return rc;
+    Entry en((void *)stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    int rc = LW_OK;
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t *d_scalars = scalars;
     if (host_scalars && n) {

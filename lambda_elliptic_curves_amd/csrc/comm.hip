@@ -1,0 +1,391 @@
+// Multi-GPU sharding of the hot path behind the C ABI: one process per GPU, a library-owned RCCL
+// communicator over xGMI, no torch types.  The reference has no multi-device code at all; what these entry
+// points return is exactly what the single-device entry points return on the concatenated input.
+//
+//   * lw_hip_ntt_sharded_device   one 2^L-point transform (or `batch` of them) block-distributed over G = 2/4/8 ranks,
+//                                 M = N/G elements each.  Bailey four-step with N1 = G:
+//                                   A  all-to-all   slice h of my block -> rank h            (RCCL send/recv group)
+//                                   B  cross step   G-point transform across the received chunks + w_N^(j2 k1)  (ntt_cross.hip)
+//                                   C  all-to-all   row k1 -> rank k1
+//                                   D  local M-point NTT  -> X[g + G*k2]                     (the single-GPU pass kernels)
+//                                   E  all-to-all + F local interleave -> my block of the natural-order result (optional)
+//                                 xGMI is a full mesh, so each all-to-all drives all G-1 links of a GPU at once; the payload
+//                                 per rank and exchange is (G-1)/G of the local shard.
+//   * lw_hip_msm_sharded_device   points/scalars sharded; every rank runs the whole Pippenger on its shard and the G
+//                                 partial sums (one point each) are all-gathered and added — RCCL has no user-defined
+//                                 reduction, so the north star's "bucket all-reduce" is an all-gather of tiny payloads
+//                                 followed by <= 7 group additions.
+//
+// The exchange schedule is written once against a small transport interface with two implementations: RCCL (one rank
+// per process) and an in-process simulator that walks all G virtual ranks on ONE device with device-to-device copies
+// (lw_hip_ntt_sharded_selftest_device) — that is how the index arithmetic below is parity-tested on a one-GPU box.
+// librccl is opened with dlopen at lw_hip_comm_init, so the library still loads on hosts without RCCL; every failure on
+// this path is reported as LW_ERR_COMM.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+#include <vector>
+#include "context.h"
+
+namespace lw {
+
+int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                      uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream, uint32_t in_log2);
+int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
+                     uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
+                     uint32_t batch, uint64_t batch_stride, hipStream_t stream);
+int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
+               hipStream_t stream, int scalars_montgomery, int affine_points);
+int msm_sum_points_host(lw_curve_t curve, const void *pts, size_t n, void *out);   // msm.hip
+uint32_t field_two_adicity(lw_field_t f);                                          // api.hip
+int check_field_layout(lw_field_t field, lw_layout_t layout);                      // api.hip
+
+// ---------------------------------------------------------------- RCCL, loaded on demand
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.handle) return LW_OK;
+    // A process that already carries an RCCL (e.g. torch's) gets that one back: dlopen matches loaded objects by SONAME.
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) {
+        set_error("cannot load librccl (%s); multi-GPU entry points are unavailable", dlerror());
+        return LW_ERR_COMM;
+    }
+    Rccl r;
+    r.handle = h;
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(h, name); if (!p) ok = false; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) {
+        set_error("librccl lacks a required symbol");
+        dlclose(h);
+        return LW_ERR_COMM;
+    }
+    g_rccl = r;
+    return LW_OK;
+}
+
+#define LW_NCCL_CHECK(expr)                                                                                  \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) {                                                                             \
+            ::lw::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__);  \
+            return LW_ERR_COMM;                                                                              \
+        }                                                                                                    \
+    } while (0)
+
+struct CommState {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 0;
+};
+static CommState g_comm;
+
+void comm_release(Context &) {
+    if (g_comm.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g_comm.comm);
+    g_comm = CommState{};
+}
+
+// ---------------------------------------------------------------- transports
+// all_to_all: for every local rank g, batch b and peer h, chunk (b, h) of g's send buffer becomes chunk (b, g) of h's
+// receive buffer.  Chunks are `chunk_bytes` long; consecutive b are `bstride_bytes` apart.
+struct Transport {
+    int G = 1;
+    int first = 0, nlocal = 1;   // ranks [first, first + nlocal) live in this process
+    virtual int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
+                           hipStream_t s) = 0;
+    virtual ~Transport() {}
+};
+
+struct RcclTransport : Transport {
+    RcclTransport() { G = g_comm.nranks; first = g_comm.rank; nlocal = 1; }
+    int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
+                   hipStream_t s) override {
+        LW_NCCL_CHECK(g_rccl.GroupStart());
+        for (uint32_t b = 0; b < batch; b++)
+            for (int h = 0; h < G; h++) {
+                ncclResult_t r1 = g_rccl.Send(send[0] + b * bstride_bytes + (size_t)h * chunk_bytes, chunk_bytes, ncclChar, h, g_comm.comm, s);
+                ncclResult_t r2 = g_rccl.Recv(recv[0] + b * bstride_bytes + (size_t)h * chunk_bytes, chunk_bytes, ncclChar, h, g_comm.comm, s);
+                if (r1 != ncclSuccess || r2 != ncclSuccess) {
+                    (void)g_rccl.GroupEnd();
+                    set_error("ncclSend/ncclRecv to rank %d failed: %s", h, g_rccl.GetErrorString(r1 != ncclSuccess ? r1 : r2));
+                    return LW_ERR_COMM;
+                }
+            }
+        LW_NCCL_CHECK(g_rccl.GroupEnd());
+        return LW_OK;
+    }
+};
+
+struct SimTransport : Transport {   // G virtual ranks on one device
+    explicit SimTransport(int g) { G = g; first = 0; nlocal = g; }
+    int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
+                   hipStream_t s) override {
+        for (int g = 0; g < G; g++)
+            for (uint32_t b = 0; b < batch; b++)
+                for (int h = 0; h < G; h++)
+                    LW_HIP_CHECK(hipMemcpyAsync(recv[h] + b * bstride_bytes + (size_t)g * chunk_bytes,
+                                                send[g] + b * bstride_bytes + (size_t)h * chunk_bytes, chunk_bytes,
+                                                hipMemcpyDeviceToDevice, s), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+};
+
+// ---------------------------------------------------------------- step F: local interleave
+// out[b][k2 * G + k1] = in[b][k1 * sl + k2]: the third exchange delivers, from every rank k1, the slice k2 in
+// [g*sl, (g+1)*sl) of its cyclic shard X[k1 + G*k2]; natural index within my block is (k2 - g*sl)*G + k1.
+template <class VEC, int VPE>
+__global__ void shard_interleave_kernel(const VEC *in, VEC *out, uint32_t lg, uint64_t sl, uint64_t in_bstride, uint64_t out_bstride) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // output vector index within one batch entry
+    const uint64_t o = t / VPE, v = t % VPE;
+    if (o >= (sl << lg)) return;
+    const uint64_t k1 = o & ((1ull << lg) - 1), k2 = o >> lg;
+    out[((uint64_t)blockIdx.y * out_bstride + o) * VPE + v] = in[((uint64_t)blockIdx.y * in_bstride + k1 * sl + k2) * VPE + v];
+}
+
+static int launch_interleave(Context &c, size_t eb, const void *in, void *out, uint32_t lg, uint64_t sl, uint32_t batch,
+                             uint64_t in_bstride, uint64_t out_bstride, hipStream_t s) {
+    const uint64_t M = sl << lg;
+    hipEvent_t pe = c.prof_begin(s);
+    if (eb == 32) {
+        dim3 grid((uint32_t)((2 * M + 255) / 256), batch);
+        hipLaunchKernelGGL((shard_interleave_kernel<uint4, 2>), grid, dim3(256), 0, s, (const uint4 *)in, (uint4 *)out, lg, sl, in_bstride, out_bstride);
+    } else if (eb == 8) {
+        dim3 grid((uint32_t)((M + 255) / 256), batch);
+        hipLaunchKernelGGL((shard_interleave_kernel<uint64_t, 1>), grid, dim3(256), 0, s, (const uint64_t *)in, (uint64_t *)out, lg, sl, in_bstride, out_bstride);
+    } else {
+        dim3 grid((uint32_t)((M + 255) / 256), batch);
+        hipLaunchKernelGGL((shard_interleave_kernel<uint32_t, 1>), grid, dim3(256), 0, s, (const uint32_t *)in, (uint32_t *)out, lg, sl, in_bstride, out_bstride);
+    }
+    c.prof_end("shard_interleave_kernel", pe, s);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+// ---------------------------------------------------------------- the schedule
+// in[i] / out[i]: buffers of local rank first + i; batch entries in_bstride / out_bstride elements apart.
+static int ntt_sharded_run(Context &c, Transport &tp, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const char *const *in,
+                           char *const *out, uint64_t in_bstride, uint64_t out_bstride, uint32_t L, uint32_t batch, int natural,
+                           hipStream_t s) {
+    const int G = tp.G;
+    uint32_t lg = 0;
+    while ((1 << lg) < G) lg++;
+    if ((1 << lg) != G || lg > 3) {
+        set_error("sharded NTT supports 1, 2, 4 or 8 ranks (got %d)", G);
+        return LW_ERR_BAD_ARG;
+    }
+    if (L < 2 * lg) {
+        set_error("2^%u elements cannot be block-distributed and sliced over %d ranks", L, G);
+        return LW_ERR_BAD_ARG;
+    }
+    const size_t eb = lw_hip_field_elem_bytes(field, layout);
+    const uint64_t M = 1ull << (L - lg), sl = M >> lg;
+    const int nl = tp.nlocal;
+    const size_t per_rank = (size_t)batch * M * eb;
+    if (c.shard_a.ensure(per_rank * nl) || c.shard_b.ensure(per_rank * nl)) return LW_ERR_ALLOC;
+    std::vector<const char *> src(nl);
+    std::vector<char *> a(nl), b(nl);
+    for (int i = 0; i < nl; i++) {
+        a[i] = (char *)c.shard_a.p + per_rank * i;
+        b[i] = (char *)c.shard_b.p + per_rank * i;
+    }
+    int rc;
+    if (G == 1) {   // degenerate: one exchange with myself, so that a 1-rank communicator still exercises the transport
+        if (in_bstride != M) {
+            set_error("1-rank sharded NTT needs a dense batch");
+            return LW_ERR_BAD_ARG;
+        }
+        rc = tp.all_to_all(in, a.data(), M * eb, batch, M * eb, s);
+        if (rc) return rc;
+        return ntt_device_locked(c, field, layout, dir, a[0], out[0], L, batch, out_bstride, nullptr, s, 0xffffffffu);
+    }
+    // A: slice h of my block -> rank h.  The caller's batch stride applies to the send side only, so strided inputs
+    // (the simulator's full-vector layout) are first exchanged batch entry by batch entry.
+    if (in_bstride == M) {
+        rc = tp.all_to_all(in, a.data(), sl * eb, batch, M * eb, s);
+        if (rc) return rc;
+    } else {
+        for (uint32_t bi = 0; bi < batch; bi++) {
+            std::vector<const char *> s1(nl);
+            std::vector<char *> r1(nl);
+            for (int i = 0; i < nl; i++) { s1[i] = in[i] + (size_t)bi * in_bstride * eb; r1[i] = a[i] + (size_t)bi * M * eb; }
+            rc = tp.all_to_all(s1.data(), r1.data(), sl * eb, 1, 0, s);
+            if (rc) return rc;
+        }
+    }
+    // B: cross-shard step on my j2 slice [g*sl, (g+1)*sl)
+    for (int i = 0; i < nl; i++) {
+        const uint64_t g = (uint64_t)(tp.first + i);
+        rc = ntt_cross_device(c, field, layout, dir, a[i], b[i], L, lg, g * sl, sl, sl, batch, M, s);
+        if (rc) return rc;
+    }
+    // C: row k1 -> rank k1
+    for (int i = 0; i < nl; i++) src[i] = b[i];
+    rc = tp.all_to_all(src.data(), a.data(), sl * eb, batch, M * eb, s);
+    if (rc) return rc;
+    // D: local M-point transform: z[k2] = X[g + G*k2]
+    for (int i = 0; i < nl; i++) {
+        rc = natural ? ntt_device_locked(c, field, layout, dir, a[i], b[i], L - lg, batch, M, nullptr, s, 0xffffffffu)
+                     : ntt_device_locked(c, field, layout, dir, a[i], out[i], L - lg, batch, out_bstride, nullptr, s, 0xffffffffu);
+        if (rc) return rc;
+    }
+    if (!natural) return LW_OK;
+    // E: slice h of my cyclic shard -> rank h;  F: interleave into natural order
+    for (int i = 0; i < nl; i++) src[i] = b[i];
+    rc = tp.all_to_all(src.data(), a.data(), sl * eb, batch, M * eb, s);
+    if (rc) return rc;
+    for (int i = 0; i < nl; i++) {
+        rc = launch_interleave(c, eb, a[i], out[i], lg, sl, batch, M, out_bstride, s);
+        if (rc) return rc;
+    }
+    return LW_OK;
+}
+
+static int check_sharded_args(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t L) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (dir != LW_DIR_FORWARD && dir != LW_DIR_INVERSE) { set_error("bad direction %d", (int)dir); return LW_ERR_BAD_ARG; }
+    if (L > 63) { set_error("order %u > 63", L); return LW_ERR_ORDER_TOO_LARGE; }
+    if (L > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", L); return LW_ERR_ROOT_OF_UNITY; }
+    if (!in || !out) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
+    return LW_OK;
+}
+
+}  // namespace lw
+
+using namespace lw;
+
+extern "C" {
+
+int lw_hip_comm_unique_id(uint8_t *out_id) {
+    if (!out_id) { set_error("null argument"); return LW_ERR_BAD_ARG; }
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    int rc = rccl_load();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == LW_HIP_COMM_ID_BYTES, "lw_hip.h: LW_HIP_COMM_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId id;
+    LW_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    memcpy(out_id, &id, sizeof(id));
+    return LW_OK;
+}
+
+int lw_hip_comm_init(const uint8_t *unique_id, int rank, int nranks) {
+    if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad communicator arguments (rank %d of %d)", rank, nranks); return LW_ERR_BAD_ARG; }
+    if (nranks & (nranks - 1) || nranks > 8) { set_error("communicator size %d: the sharded paths take 1, 2, 4 or 8 ranks (one node)", nranks); return LW_ERR_BAD_ARG; }
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    int rc = rccl_load();
+    if (rc) return rc;
+    comm_release(en.c);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    LW_NCCL_CHECK(g_rccl.CommInitRank(&comm, nranks, id, rank));   // binds to the context's device (Entry set it)
+    g_comm.comm = comm;
+    g_comm.rank = rank;
+    g_comm.nranks = nranks;
+    return LW_OK;
+}
+
+int lw_hip_comm_shutdown(void) {
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    (void)hipDeviceSynchronize();
+    comm_release(en.c);
+    return LW_OK;
+}
+
+int lw_hip_comm_info(int *rank, int *nranks) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> g(c.mu);
+    if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
+    if (rank) *rank = g_comm.rank;
+    if (nranks) *nranks = g_comm.nranks;
+    return LW_OK;
+}
+
+int lw_hip_ntt_sharded_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_local, void *d_out_local,
+                              uint32_t log2n_total, uint32_t batch, int natural_output, void *hip_stream) {
+    int rc = check_sharded_args(field, layout, dir, d_in_local, d_out_local, log2n_total);
+    if (rc) return rc;
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
+    if (batch == 0) return LW_OK;
+    RcclTransport tp;
+    uint32_t lg = 0;
+    while ((1 << lg) < tp.G) lg++;
+    if (log2n_total < lg) { set_error("2^%u elements over %d ranks", log2n_total, tp.G); return LW_ERR_BAD_ARG; }
+    const uint64_t M = 1ull << (log2n_total - lg);
+    const char *in[1] = {(const char *)d_in_local};
+    char *out[1] = {(char *)d_out_local};
+    return ntt_sharded_run(en.c, tp, field, layout, dir, in, out, M, M, log2n_total, batch, natural_output, en.stream);
+}
+
+int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                                       uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output, void *hip_stream) {
+    int rc = check_sharded_args(field, layout, dir, d_in_full, d_out_full, log2n_total);
+    if (rc) return rc;
+    if (log2_shards < 1 || log2_shards > 3) { set_error("self-test takes 2, 4 or 8 virtual ranks"); return LW_ERR_BAD_ARG; }
+    if (d_in_full == d_out_full) { set_error("self-test needs distinct buffers"); return LW_ERR_BAD_ARG; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    if (batch == 0) return LW_OK;
+    SimTransport tp(1 << log2_shards);
+    if (log2n_total < 2 * log2_shards) { set_error("2^%u elements over %d ranks", log2n_total, tp.G); return LW_ERR_BAD_ARG; }
+    const size_t eb = lw_hip_field_elem_bytes(field, layout);
+    const uint64_t N = 1ull << log2n_total, M = N >> log2_shards;
+    std::vector<const char *> in(tp.G);
+    std::vector<char *> out(tp.G);
+    for (int g = 0; g < tp.G; g++) {
+        in[g] = (const char *)d_in_full + (size_t)g * M * eb;
+        out[g] = (char *)d_out_full + (size_t)g * M * eb;
+    }
+    return ntt_sharded_run(en.c, tp, field, layout, dir, in.data(), out.data(), N, N, log2n_total, batch, natural_output, en.stream);
+}
+
+int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n_local, void *out_point_host,
+                              void *hip_stream) {
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    if (pb == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
+    Context &c = en.c;
+    std::vector<char> part(pb), all(pb * g_comm.nranks);
+    int rc = msm_device(c, curve, d_scalars, d_points, n_local, part.data(), en.stream, 0, 0);
+    if (rc) return rc;
+    // all-gather of one point per rank, then <= 7 group additions on the host (same limb code as the device)
+    if (c.shard_a.ensure(pb * (g_comm.nranks + 1))) return LW_ERR_ALLOC;
+    char *d_send = (char *)c.shard_a.p, *d_recv = d_send + pb;
+    LW_HIP_CHECK(hipMemcpyAsync(d_send, part.data(), pb, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
+    LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, pb, ncclChar, g_comm.comm, en.stream));
+    LW_HIP_CHECK(hipMemcpyAsync(all.data(), d_recv, pb * g_comm.nranks, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
+    return msm_sum_points_host(curve, all.data(), (size_t)g_comm.nranks, out_point_host);
+}
+
+}  // extern "C"

@@ -10,6 +10,14 @@
 #include <vector>
 #include "../../include/lw_hip.h"
 
+// Ablation switches (skip butterflies / loads / stores: WRONG results, timing only) exist only in builds made with
+// -DLW_HIP_ABLATION (tools/ab_ntt.sh); in the shipped library LW_DBG() is the constant 0 and the branches fold away.
+#ifdef LW_HIP_ABLATION
+#define LW_DBG(p) ((p).dbg)
+#else
+#define LW_DBG(p) 0u
+#endif
+
 namespace lw {
 
 void set_error(const char *fmt, ...);
@@ -75,6 +83,27 @@ struct Context {
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     lw_timings_t timings = {};
+    // Cross-stream ordering of the context-owned buffers (scratch, tables, staging, MSM workspace): every entry point
+    // records `order_event` on its launch stream when it returns; a call arriving on a different stream first makes
+    // that stream wait for it.  (c.mu only serialises the host side.)
+    hipEvent_t order_event = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    DeviceBuf shard_a, shard_b;       // exchange buffers of the sharded (multi-GPU) entry points
+    void release_all();               // frees every cached device object (shutdown / device change)
+};
+
+// Held by every extern "C" entry point for its whole duration: context lock, lazy init, device binding (the HIP
+// current device is per thread) and the cross-stream ordering above.
+struct Entry {
+    Context &c;
+    std::unique_lock<std::mutex> lock;
+    hipStream_t stream;
+    int rc = LW_OK;
+    int prev_device = -1;
+    explicit Entry(void *hip_stream);
+    ~Entry();
+    Entry(const Entry &) = delete;
 };
 
 Context &ctx();

@@ -433,6 +433,23 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     return rc;
 }
 
+// Sum of a few projective points on the host, normalised like every MSM result (the combine step of the sharded MSM).
+template <class C>
+static void sum_points_host_t(const void *pts, size_t n, void *out) {
+    Point<C> acc = pt_identity<C>();
+    for (size_t i = 0; i < n; i++) acc = pt_add<C>(acc, pt_load<C>((const char *)pts + i * 3 * C::B::BYTES));
+    pt_store<C>(out, pt_to_affine<C>(acc));
+}
+int msm_sum_points_host(lw_curve_t curve, const void *pts, size_t n, void *out) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: sum_points_host_t<Bls12381G1>(pts, n, out); return LW_OK;
+        case LW_CURVE_BN254_G1: sum_points_host_t<Bn254G1>(pts, n, out); return LW_OK;
+        case LW_CURVE_BN254_G2: sum_points_host_t<Bn254G2>(pts, n, out); return LW_OK;
+        case LW_CURVE_BLS12_381_G2: sum_points_host_t<Bls12381G2>(pts, n, out); return LW_OK;
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
+
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream) {
     switch (curve) {
         case LW_CURVE_BLS12_381_G1: return msm_normalize_bls12381_g1(c, stream, d_in, n, d_out);

@@ -33,7 +33,7 @@ struct BbPassParams {
     uint32_t nsteps;
     uint32_t k[8];
     uint32_t scale, sc;        // N^-1 (R = 2^32 domain) on the last pass of an inverse transform
-    uint32_t dbg;              // diagnostics (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip loads, bit2 skip stores, bit3 old last-pass mapping
+    uint32_t dbg;              // ablation builds only (-DLW_HIP_ABLATION): bit0 skip butterflies, bit1 skip loads, bit2 skip stores, bit3 old last-pass mapping
 };
 
 __device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
@@ -61,7 +61,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
     // input (column, row, component); in the later ones it keeps the lanes of a wave inside a few columns, whose
     // twiddles T[(hi_c << t) | x] are then neighbours in the table (columns-fastest made every lane fetch a different
     // cache line).  LDS slots are XOR-swizzled by row bits (lds_slot) so rows-fastest accesses spread over the banks.
-    const bool rows_fastest = LAST && (step == 0 || !(p.dbg & 8));
+    const bool rows_fastest = LAST && (step == 0 || !(LW_DBG(p) & 8));
     uint32_t c, mr;
     if (rows_fastest) {
         const uint32_t comp = w & ((1u << lgV) - 1);
@@ -71,7 +71,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
         c = w & ((1u << logC) - 1);
         mr = w >> logC;
     }
-    const uint32_t swz = (LAST && !(p.dbg & 8)) ? ((1u << logC) - 1) : 0u;
+    const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;
     const uint32_t m_low = mr & ((1u << sh) - 1);
     const uint32_t m_high = mr >> sh;
     const uint32_t mbase = (m_high << (sh + K)) | m_low;
@@ -87,12 +87,12 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             uint32_t g;
             if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + (m << lgS) + c;
-            x[j] = (p.dbg & 2) ? g : bb_load_word<W64>(gin, g);
+            x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<W64>(gin, g);
         } else {
             x[j] = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
         }
     }
-    if (!(p.dbg & 1))
+    if (!(LW_DBG(p) & 1))
 #pragma unroll
     for (int u = 0; u < K; u++) {
         const int half = 1 << (K - 1 - u);
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         uint32_t g;
         if (!LAST) g = base + (m << lgS) + c;
         else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
-        const uint32_t swz = (LAST && !(p.dbg & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
-        if (!(p.dbg & 4)) bb_store_word<W64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
+        const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
+        if (!(LW_DBG(p) & 4)) bb_store_word<W64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
     }
 }
 

@@ -148,7 +148,7 @@ static int cross256(Context &c, int field, lw_dir_t dir, const void *d_in, void 
                     hipStream_t stream) {
     int rc = LW_OK;
     CrossParams p{};
-    p.tw = ntt256_twiddle_table(c, field, dir, log2_total, stream, &rc);
+    p.tw = ntt256_twiddle_table(c, field, dir, lg, stream, &rc);   // only T[0..G/2) is read: any cached table serves (prefix property)
     if (rc) return rc;
     uint32_t wN[8];
     rc = ntt256_root_words(field, log2_total, dir == LW_DIR_INVERSE, wN);
@@ -187,7 +187,7 @@ static int cross_bb(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, vo
                     hipStream_t stream) {
     int rc = LW_OK;
     CrossParamsBb p{};
-    p.tw = ntt_bb_twiddle_table(c, dir, log2_total, stream, &rc);
+    p.tw = ntt_bb_twiddle_table(c, dir, lg, stream, &rc);   // only T[0..G/2) is read
     if (rc) return rc;
     p.wN = ntt_bb_root(log2_total, dir == LW_DIR_INVERSE);
     p.lgV = lgV;

@@ -6,7 +6,8 @@
 // every field op returns the canonical residue, results are byte-identical to the reference however
 // the stages are scheduled; here they are scheduled for the GPU:
 //
-//   * log2(N) stages are cut into passes of r <= 11 stages.  One workgroup owns a tile of 2^r "rows"
+//   * log2(N) stages are cut into passes of r <= 8 stages (the staged twiddles ltw[2][256] and the 17p lazy bound
+//     both need r <= 8; ntt_set_max_pass_stages enforces it).  One workgroup owns a tile of 2^r "rows"
 //     (the index bits the pass's stages touch) x C adjacent "columns" (contiguous elements), stages it in
 //     LDS once and runs all r stages there: a pass costs one HBM read + one HBM write of the vector,
 //     versus one round trip per stage in the reference's CUDA path (math/src/fft/gpu/cuda/ops.rs:28-38).
@@ -55,7 +56,7 @@ struct NttPassParams {
     uint32_t cos_out;      // last pass of an inverse transform: multiply natural output i by h^-i * N^-1 (folded into cos_hi)
     uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
-    uint32_t dbg;          // diagnostics only (LW_HIP_NTT_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores (results are wrong)
+    uint32_t dbg;          // ablation builds only (-DLW_HIP_ABLATION, see LW_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -139,7 +140,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         uint4 q0, q1;
         if (step == 0) {
             uint64_t g = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
-            if (p.dbg & 2) {
+            if (LW_DBG(p) & 2) {
                 q0 = make_uint4(m, c, 1, 2);
                 q1 = make_uint4(3, 4, 5, 6);
             } else {
@@ -185,7 +186,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         Fe<F> tw;
         if (LAST) {
             const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
-            tw = tw_load<F>(p.tw, (p.dbg & 32) ? ((gt | (uint32_t)jt) & 0xff) : (gt | (uint32_t)jt));
+            tw = tw_load<F>(p.tw, (LW_DBG(p) & 32) ? ((gt | (uint32_t)jt) & 0xff) : (gt | (uint32_t)jt));
         } else {   // slot 2^t - 1 + x of the staged table
             const uint32_t li = (1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt);
             uint4 a = ltw[0][li], b = ltw[1][li];
@@ -194,7 +195,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
         return tw;
     };
-    if (!(p.dbg & 1)) {
+    if (!(LW_DBG(p) & 1)) {
         Fe<F> tw_next = fetch_tw(0);
 #pragma unroll
         for (int q = 0; q < E - 1; q++) {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         uint64_t g;
         if (!LAST) g = base + ((uint64_t)m << lgS) + c;
         else g = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)b << logC) + c;
-        if (!(p.dbg & 4)) gout[2 * g + plane] = lds[plane][e];
+        if (!(LW_DBG(p) & 4)) gout[2 * g + plane] = lds[plane][e];
     }
 }
 

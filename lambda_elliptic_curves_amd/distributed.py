@@ -13,9 +13,12 @@ single-device API on the concatenated input.
                 "bucket all-reduce" of the north star is an all-gather + local group adds of tiny payloads.
 * batches with batch >= G need no collective: give each rank whole columns (fft.ntt_device per rank).
 
-`comm` abstracts the process group so the same SPMD code runs under torch.distributed (NCCL = RCCL on ROCm,
-or gloo on CPU for tests) and under an in-process simulator of G virtual ranks (tests on a single GPU).
-`backend` abstracts the local compute; the default is the HIP library (there is no CPU fallback).
+The production path is `HipComm`: the communicator and the whole exchange schedule live INSIDE the C library
+(csrc/comm.hip: lw_hip_comm_init, lw_hip_ntt_sharded_device, lw_hip_msm_sharded_device — RCCL send/recv groups and
+all-gather issued from C++), so a Rust caller reaches the multi-GPU path through the same extern "C" boundary and this
+module is only a thin caller.  `TorchDistComm` / `SimComm` run the same schedule in Python over torch.distributed (gloo
+on CPU for tests) or G in-process virtual ranks; `backend` abstracts their local compute (default: the HIP library;
+there is no CPU fallback).
 """
 import ctypes as C
 
@@ -26,6 +29,49 @@ from .errors import check
 
 
 # ---------------------------------------------------------------- communicators
+class HipComm:
+    """Library-owned RCCL communicator (include/lw_hip.h "Multi-GPU").  `unique_id` is the 128-byte id rank 0 got from
+    HipComm.unique_id() and handed to the other processes out of band (ncclGetUniqueId's contract);
+    HipComm.from_torch_dist() does that hand-over with torch.distributed's broadcast."""
+
+    def __init__(self, unique_id, rank, size):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        check(L.lib().lw_hip_comm_init(buf, rank, size))
+        self.rank, self.size = rank, size
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(L.lib().lw_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_dist(cls, group=None):
+        import torch.distributed as dist
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], rank, size)
+
+    def close(self):
+        check(L.lib().lw_hip_comm_shutdown())
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ntt_sharded_selftest(field, x_full, log2n_total, log2_shards, inverse=False, natural_output=True, batch=1):
+    """lw_hip_ntt_sharded_selftest_device: the C++ exchange schedule with 2^log2_shards virtual ranks on one device."""
+    import torch
+    out = torch.empty_like(x_full)
+    check(L.lib().lw_hip_ntt_sharded_selftest_device(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD,
+                                                     C.c_void_p(x_full.data_ptr()), C.c_void_p(out.data_ptr()), log2n_total,
+                                                     log2_shards, batch, 1 if natural_output else 0, _stream_ptr()))
+    return out
+
+
 class TorchDistComm:
     """torch.distributed process group (backend 'nccl' is RCCL on ROCm; 'gloo' for CPU tests)."""
 
@@ -127,10 +173,18 @@ def _log2(n):
 
 
 # ---------------------------------------------------------------- sharded NTT
-def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, natural_output=True):
+def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, natural_output=True, batch=1):
     """x_local: this rank's contiguous block of the natural-order vector, tensor [M, words] (M = N / G).
     Returns this rank's block of the natural-order result (natural_output=True), or the cyclic shard
-    X[rank + G*k2] (one exchange fewer; convenient when a bit-reverse + commit follows)."""
+    X[rank + G*k2] (one exchange fewer; convenient when a bit-reverse + commit follows).  `batch` > 1 (HipComm only):
+    x_local holds `batch` blocks of M elements back to back."""
+    if isinstance(comm, HipComm):   # production path: the schedule runs in C++ over the library's RCCL communicator
+        import torch
+        out = torch.empty_like(x_local)
+        check(L.lib().lw_hip_ntt_sharded_device(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD,
+                                                C.c_void_p(x_local.data_ptr()), C.c_void_p(out.data_ptr()), log2n_total, batch,
+                                                1 if natural_output else 0, _stream_ptr()))
+        return out
     backend = backend or HipBackend()
     G, g = comm.size, comm.rank
     if G == 1:
@@ -162,6 +216,11 @@ def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, 
 def msm_sharded(curve, t_scalars, t_points, n_local, comm, backend=None):
     """Every rank holds n_local (scalar, point) pairs; returns sum over all ranks' pairs on every rank."""
     import torch
+    if isinstance(comm, HipComm):   # production path: local Pippenger + RCCL all-gather + final adds inside the library
+        out = np.zeros(curve.point_words, dtype=np.uint64)
+        check(L.lib().lw_hip_msm_sharded_device(curve.curve, C.c_void_p(t_scalars.data_ptr()), C.c_void_p(t_points.data_ptr()),
+                                                n_local, out.ctypes.data_as(C.c_void_p), _stream_ptr()))
+        return out
     backend = backend or HipBackend()
     part = backend.local_msm(curve, t_scalars, t_points, n_local)          # numpy projective point
     if comm.size == 1:

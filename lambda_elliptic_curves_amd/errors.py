@@ -24,6 +24,10 @@ class HipError(FFTError):
     """FFTError::<backend>Error — device not found / allocation / launch failures"""
 
 
+class CommError(HipError):
+    """LW_ERR_COMM — RCCL unavailable, no communicator, or a failing collective (multi-GPU entry points)"""
+
+
 class MSMError(Exception):
     pass
 
@@ -42,6 +46,7 @@ _MAP = {
     L.ERR_ROOT_OF_UNITY: RootOfUnityError,
     L.ERR_LENGTH_MISMATCH: LengthMismatch,
     L.ERR_INV_ZERO: FieldError,
+    L.ERR_COMM: CommError,
 }
 
 

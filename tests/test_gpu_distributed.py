@@ -73,3 +73,101 @@ def test_sharded_msm_four_virtual_ranks():
     exp = O.point_to_affine_ints(oid, O.parallel_msm_with(oid, scalars, points, 9, 8))
     for r in range(G):
         assert O.point_to_affine_ints(oid, outs[r]) == exp
+
+
+# ---------------------------------------------------------------- the C++ schedule behind the C ABI (csrc/comm.hip)
+def _as_t(a):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
+
+
+@pytest.mark.parametrize("name", ["stark252", "fr381", "babybear_u32", "babybear_u64", "babybear_ext4"])
+@pytest.mark.parametrize("lg,L", [(1, 10), (2, 13), (3, 16), (3, 6)])
+def test_library_sharded_schedule_selftest_matches_oracle(name, lg, L):
+    # lw_hip_ntt_sharded_selftest_device: the exchange schedule RCCL runs, with 2^lg virtual ranks on this one GPU
+    from lambda_elliptic_curves_amd import distributed as D
+    fld, oid = util.field_pairs()[name]
+    n, G = 1 << L, 1 << lg
+    M = n // G
+    full = util.rand_elems(name, n, 140 + L)
+    exp = O.fft(oid, full, O.get_twiddles(oid, L, O.ROOTS_BITREV))
+    t = _as_t(full)
+    nat = D.ntt_sharded_selftest(fld, t, L, lg)
+    cyc = D.ntt_sharded_selftest(fld, t, L, lg, natural_output=False)
+    back = D.ntt_sharded_selftest(fld, nat, L, lg, inverse=True)
+    torch.cuda.synchronize()
+    view = lambda x: x.cpu().numpy().view(full.dtype).reshape(full.shape)
+    assert np.array_equal(view(nat), exp)
+    cyc = view(cyc)
+    for g in range(G):
+        assert np.array_equal(cyc[g * M:(g + 1) * M], exp[g::G])
+    assert np.array_equal(view(back), full)
+
+
+def test_library_sharded_schedule_selftest_config4_shape():
+    # BASELINE config 4: 4 BabyBear columns x 2^24 over 8 ranks (2^21 elements per rank and column), one batched call;
+    # every column equals the single-device transform, which test_gpu_parity_full pins to the oracle at this size
+    from lambda_elliptic_curves_amd import distributed as D
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()["babybear_u32"]
+    L, B = 24, 4
+    full = util.rand_elems("babybear_u32", B << L, 99)
+    t = _as_t(full)
+    got = D.ntt_sharded_selftest(fld, t, L, 3, batch=B)
+    ref = torch.empty_like(t)
+    fft.ntt_device(fld, t, ref, L, batch=B)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    col = O.evaluate_fft(oid, full[: 1 << L])
+    assert np.array_equal(got[: 1 << L].cpu().numpy().view(np.uint32), np.asarray(col).reshape(-1))
+
+
+def test_library_sharded_large_stark252_2_22_over_8():
+    from lambda_elliptic_curves_amd import distributed as D
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()["stark252"]
+    L = 22
+    full = util.rand_elems("stark252", 1 << L, 98)
+    t = _as_t(full)
+    got = D.ntt_sharded_selftest(fld, t, L, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), O.evaluate_fft(oid, full))
+
+
+def test_rccl_communicator_one_rank_through_the_c_abi():
+    # The library-owned RCCL communicator with nranks = 1: librccl is loaded, ncclCommInitRank runs, and the sharded
+    # entry points go through ncclSend/ncclRecv (to self) and ncclAllGather on the real transport.
+    from lambda_elliptic_curves_amd import distributed as D
+    from lambda_elliptic_curves_amd import errors, msm
+    from lambda_elliptic_curves_amd import _lib as L_
+    import ctypes as C
+    L_.lib().lw_hip_comm_shutdown()
+    fld, oid = util.field_pairs()["stark252"]
+    a = util.rand_elems("stark252", 1 << 14, 5)
+    t = _as_t(a)
+    out = torch.empty_like(t)
+    rc = L_.lib().lw_hip_ntt_sharded_device(fld.field, fld.layout, 0, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), 14, 1, 1, None)
+    assert rc == L_.ERR_COMM                        # no communicator yet
+    with pytest.raises(errors.CommError):
+        errors.check(rc)
+    comm = D.HipComm(D.HipComm.unique_id(), 0, 1)
+    try:
+        r, n = C.c_int(-1), C.c_int(-1)
+        assert L_.lib().lw_hip_comm_info(C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (0, 1)
+        got = D.ntt_sharded(fld, t, 14, comm)
+        back = D.ntt_sharded(fld, got, 14, comm, inverse=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().view(np.uint64), O.evaluate_fft(oid, a))
+        assert np.array_equal(back.cpu().numpy().view(np.uint64), a)
+        bb, boid = util.field_pairs()["babybear_u32"]
+        cols = util.rand_elems("babybear_u32", 4 << 12, 6)
+        gb = D.ntt_sharded(bb, _as_t(cols), 12, comm, batch=4)
+        torch.cuda.synchronize()
+        for c in range(4):
+            assert np.array_equal(gb[c << 12:(c + 1) << 12].cpu().numpy().view(np.uint32),
+                                  np.asarray(O.evaluate_fft(boid, cols[c << 12:(c + 1) << 12])).reshape(-1))
+        crv, coid = util.curve_pairs()["bn254_g1"]
+        sc, pts = util.msm_case(coid, 3000, 8)
+        p = D.msm_sharded(crv, _as_t(sc), _as_t(pts), 3000, comm)
+        assert O.point_to_affine_ints(coid, p) == O.point_to_affine_ints(coid, O.msm(coid, sc, pts))
+    finally:
+        comm.close()

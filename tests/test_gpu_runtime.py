@@ -68,3 +68,51 @@ def test_many_small_columns_in_one_call():
     for b in (0, 1, 499, 999):
         assert np.array_equal(got[b * n:(b + 1) * n], O.fft(oid, a[b * n:(b + 1) * n], tw))
     assert np.array_equal(fft.ntt(fld, got, inverse=True, log2n=8, batch=batch), a)
+
+
+def test_calls_on_different_streams_share_the_context_buffers_safely():
+    # scratch / tables are context-owned; a multi-pass in-place NTT queued on a side stream must not be
+    # overtaken by the next call on another stream (here: the host-buffer path on the null stream, and a second side
+    # stream).  The library orders consecutive calls with an event (include/lw_hip.h, stream contract).
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()["stark252"]
+    L = 20
+    a = util.rand_elems("stark252", 1 << L, 71)
+    b = util.rand_elems("stark252", 1 << 18, 72)
+    exp_a = O.evaluate_fft(oid, a)
+    exp_b = O.evaluate_fft(oid, b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ta = torch.from_numpy(a.view(np.int64)).cuda()
+    tb = torch.from_numpy(b.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ta.copy_(torch.from_numpy(a.view(np.int64)))
+        tb.copy_(torch.from_numpy(b.view(np.int64)))
+        torch.cuda.synchronize()
+        fft.ntt_device(fld, ta, ta, L, stream=s1.cuda_stream)          # in place: 3 passes through c.scratch
+        got_host = fft.ntt(fld, b)                                     # null stream, same scratch and tables
+        fft.ntt_device(fld, tb, tb, 18, stream=s2.cuda_stream)         # a third stream
+        torch.cuda.synchronize()
+        assert np.array_equal(got_host, exp_b)
+        assert np.array_equal(ta.cpu().numpy().view(np.uint64), exp_a)
+        assert np.array_equal(tb.cpu().numpy().view(np.uint64), exp_b)
+
+
+def test_init_takes_one_device_per_process_and_cross_step_keeps_tables_small():
+    import torch
+    from lambda_elliptic_curves_amd import _lib
+    from lambda_elliptic_curves_amd import distributed as D
+    L = _lib.lib()
+    ids = (C.c_int * 2)(0, 1)
+    assert L.lw_hip_init(ids, 2) == _lib.ERR_BAD_ARG          # one process per GPU; sharding goes through lw_hip_comm_init
+    L.lw_hip_shutdown()
+    # a G = 8 sharded transform of 2^21 elements needs the local 2^18 table, not a 2^21 one (ntt_cross.hip)
+    fld, oid = util.field_pairs()["stark252"]
+    a = util.rand_elems("stark252", 1 << 21, 73)
+    got = D.ntt_sharded_selftest(fld, torch.from_numpy(a.view(np.int64)).cuda(), 21, 3)
+    torch.cuda.synchronize()
+    t = _lib.Timings()
+    assert L.lw_hip_get_timings(C.byref(t)) == 0
+    assert t.twiddle_bytes <= (1 << 17) * 32, t.twiddle_bytes
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), O.evaluate_fft(oid, a))

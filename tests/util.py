@@ -58,12 +58,27 @@ def generator(oid):
     return O.point_from_affine_ints(oid, c.gen[0].tup(), c.gen[1].tup())
 
 
-def msm_case(oid, n, seed):
+def msm_case(oid, n, seed, threads=1):
     """Synthetic MSM input: uniform 256-bit canonical scalars, SRS-like projective points
-    P_i = [s0 + i*delta]G built by repeated projective addition (so Z != 1), from a fixed seed."""
+    P_i = [s0 + i*delta]G — n DISTINCT points — built by repeated projective addition (so Z != 1), from a fixed seed.
+    threads > 1 builds the run in `threads` pieces concurrently (piece t starts at [s0 + t*chunk*delta]G): the same
+    group elements, different projective representatives at the piece boundaries."""
     rng = np.random.default_rng(seed)
     scalars = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
     s0 = int(rng.integers(1, 1 << 62))
     delta = int(rng.integers(1, 1 << 62))
-    points = O.gen_points(oid, generator(oid), s0, delta, n)
-    return scalars, points
+    g = generator(oid)
+    if threads <= 1 or n < 4 * threads:
+        return scalars, O.gen_points(oid, g, s0, delta, n)
+    from concurrent.futures import ThreadPoolExecutor
+    chunk = (n + threads - 1) // threads
+    spans = [(t * chunk, min(n, (t + 1) * chunk)) for t in range(threads) if t * chunk < n]
+    with ThreadPoolExecutor(len(spans)) as ex:   # ctypes releases the GIL inside the C call
+        parts = list(ex.map(lambda ab: O.gen_points(oid, g, s0 + ab[0] * delta, delta, ab[1] - ab[0]), spans))
+    return scalars, np.concatenate(parts)
+
+
+def host_threads(cap=16):
+    """Worker threads for the CPU checker on this box (the GPU box gives a one-GPU job 16 cores)."""
+    import os
+    return max(1, min(cap, os.cpu_count() or 1))
