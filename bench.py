@@ -3,16 +3,22 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input resident in HBM:
   * NTT leg (the `value`): one forward Stark252 NTT of 2^log2n elements (Polynomial::evaluate_fft backend arm),
-  * MSM leg (reported under "msm"): one BLS12-381 G1 Pippenger MSM of 2^msm_log2n points.
+  * MSM leg (reported under "msm"): one BLS12-381 G1 Pippenger MSM of 2^msm_log2n DISTINCT points.
 N > 1 (launched by torch.distributed.run, one rank per GPU), weak scaling — per-GPU work is fixed:
-  * NTT leg: ONE transform of N_gpus * 2^log2n elements block-distributed over the ranks (four-step over RCCL
-    all-to-all, lambda_elliptic_curves_amd/distributed.py); --dist-mode independent instead gives every rank its
-    own 2^log2n transform (STARK columns, no collective);
-  * MSM leg: every rank holds 2^msm_log2n (scalar, point) pairs; partial sums are combined with one all_gather.
+  * NTT leg: ONE transform of N_gpus * 2^log2n elements block-distributed over the ranks, through the library's own
+    RCCL communicator (lw_hip_comm_init + lw_hip_ntt_sharded_device, csrc/comm.hip: four-step with all-to-all);
+    --dist-mode independent instead gives every rank its own 2^log2n transform (STARK columns, no collective);
+  * MSM leg: every rank holds 2^msm_log2n (scalar, point) pairs; lw_hip_msm_sharded_device all-gathers the partial sums.
+  torch.distributed is used for the rendezvous, the barriers and the max-over-ranks only.
+
+After the timed region rank 0 (N = 1) runs the CPU oracle on the SAME inputs: single-threaded evaluate_fft at 2^log2n
+(the `cpu_baseline`), compared byte for byte with the timed GPU output ("bit_exact"), plus the all-cores context rows
+(column-parallel NTT, window-parallel MSM over the whole MSM input, also compared).  A mismatch exits non-zero.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -23,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 
 def rand_field_elems(n, seed, top_bits=59):
@@ -34,17 +40,38 @@ def rand_field_elems(n, seed, top_bits=59):
     return a
 
 
-def pmc_valu_busy(kernel_substr):
-    """Mean VALUBusy (%) of a kernel from the committed rocprofv3 counter summary, or None."""
+def latest_profile(pattern):
+    """Newest committed profiles/rNN_<pattern> (per-round naming)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return files[-1] if files else None
+
+
+def pmc_counter(kernel_substr, counter):
+    """Launch-weighted mean of a counter for a kernel from the newest committed rocprofv3 counter summary, or None."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    path = latest_profile("pmc_summary.csv")
+    if not path:
+        return None
     try:
-        rows = [r for r in csv.DictReader(open(path)) if r["counter"] == "VALUBusy" and kernel_substr in r["kernel"]]
+        rows = [r for r in csv.DictReader(open(path)) if r["counter"] == counter and kernel_substr in r["kernel"]]
         tot = sum(float(r["mean_per_launch"]) * int(r["launches"]) for r in rows)
         cnt = sum(int(r["launches"]) for r in rows)
         return tot / cnt if cnt else None
     except Exception:
         return None
+
+
+def traffic_entry(leg, log2n):
+    """(bytes per launch of the leg's dominant kernel, source) from profiles/traffic_latest.json, or (None, None)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+        ent = tj.get(leg) or (tj if leg == "ntt" and "hbm_bytes_per_launch" in tj else None)
+        if ent and ent.get("log2n") == log2n:
+            return ent.get("hbm_bytes_per_launch"), ent.get("source", "profiles/traffic_latest.json")
+    except Exception:
+        pass
+    return None, None
 
 
 def main():
@@ -56,8 +83,8 @@ def main():
     ap.add_argument("--msm-log2n", type=int, default=24, help="MSM size (BLS12-381 G1)")
     ap.add_argument("--workload", choices=["ntt", "msm", "all"], default="all")
     ap.add_argument("--dist-mode", choices=["sharded", "independent"], default="sharded")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-log2n", type=int, default=24, help="CPU baseline sample size")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (and with them the bit-exact checks)")
+    ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -79,7 +106,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from lambda_elliptic_curves_amd import _lib, fft, msm
+    from lambda_elliptic_curves_amd import _lib, fft
+    from lambda_elliptic_curves_amd import distributed as D
     import ctypes as C
     dev = C.c_int(local_rank)
     rc = _lib.lib().lw_hip_init(C.byref(dev), 1)
@@ -98,48 +126,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks_ok(ok):
+        """Collective decision: True only if every rank says True (a per-rank fallback would leave the others blocked
+        in a collective and change the measured workload silently)."""
+        if world == 1:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    # library-owned RCCL communicator for the sharded legs (the data path never goes through torch.distributed)
+    comm, comm_error = None, None
+    if world > 1 and args.dist_mode == "sharded":
+        try:
+            comm = D.HipComm.from_torch_dist()
+        except Exception as e:
+            comm_error = "%s: %s" % (type(e).__name__, str(e)[:160])
+        if not all_ranks_ok(comm is not None):
+            if comm is not None:
+                comm.close()
+            comm = None
+            comm_error = comm_error or "another rank failed to create the communicator"
+
     result = {}
+    mismatch = []
     # ------------------------------------------------------------------ NTT leg
     if args.workload in ("ntt", "all"):
         L = args.log2n
         n = 1 << L
         fld = fft.Stark252PrimeField
         host = rand_field_elems(n, 0x5EED0000 + L + 1000 * rank)
-        t_in = torch.from_numpy(host.view(np.int64)).cuda()
+        t_in = torch.from_numpy(host.view(np.int64)).cuda().view(n, 4)
         t_out = torch.empty_like(t_in)
-        del host
-        dist_mode = "single" if world == 1 else args.dist_mode
-        comm = None
-        if dist_mode == "sharded":
-            from lambda_elliptic_curves_amd import distributed as D
-            comm = D.TorchDistComm()
-            t_in = t_in.view(n, 4)
+        dist_mode = "single" if world == 1 else ("sharded" if comm is not None else "independent")
+        sharded_error = comm_error
+        Lt = L + (world.bit_length() - 1 if dist_mode == "sharded" else 0)
 
         def step():
             if dist_mode == "sharded":
-                return D.ntt_sharded(fld, t_in, L + (world.bit_length() - 1), comm)
+                return D.ntt_sharded(fld, t_in, Lt, comm)
             fft.ntt_device(fld, t_in, t_out, L)
             return t_out
 
+        ok, err = True, None
         try:
             for _ in range(args.warmup):
-                step()
-        except Exception as e:   # keep the run measurable if the collective path is unavailable on this node
+                last = step()
+            torch.cuda.synchronize()
+        except Exception as e:
+            ok, err = False, "%s: %s" % (type(e).__name__, str(e)[:160])
+        if not all_ranks_ok(ok):
             if dist_mode != "sharded":
-                raise
-            dist_mode = "independent (sharded failed: %s)" % str(e)[:120]
-            t_in = t_in.view(-1)
-            t_in = t_in.view(n, 4)
+                raise RuntimeError("NTT warm-up failed: %s" % err)
+            # every rank switches together; the line below is labelled as a different workload
+            sharded_error = err or "another rank failed in the sharded warm-up"
+            dist_mode, Lt = "independent", L
             for _ in range(args.warmup):
-                fft.ntt_device(fld, t_in, t_out, L)
+                last = step()
         barrier()
         _lib.profile_begin()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            if dist_mode == "sharded":
-                step()
-            else:
-                fft.ntt_device(fld, t_in, t_out, L)
+            last = step()
         barrier()
         dt = time.perf_counter() - t0
         prof = _lib.profile_end()
@@ -151,28 +199,22 @@ def main():
         total_ms = sum(v[1] for k, v in prof.items() if k.startswith("ntt_pass_kernel"))
         passes = max(launches // max(args.steps, 1), 1)
         avg_launch_ms = total_ms / max(launches, 1)
-        alg_bytes_per_launch = 2.0 * n * 32 / max(passes, 1)     # 2*N*B per transform, spread over its passes
+        n_local_ntt = n                                          # the local transform is 2^log2n in every mode
+        alg_bytes_per_launch = 2.0 * n_local_ntt * 32 / max(passes, 1)     # 2*N*B per transform, spread over its passes
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        traffic_src = None
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("log2n") == L:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_src = tj.get("source")
-            except Exception:
-                pass
+        traffic, traffic_src = traffic_entry("ntt", L)
         result.update({
-            "metric": "NTT elems/sec (Stark252 radix-2, 2^%d, forward, bit-exact vs CPU) [+ MSM G1 point-adds/sec under 'msm']" % L,
+            "metric": "NTT elems/sec (Stark252 radix-2, 2^%d, forward, bit-exact vs CPU: see 'bit_exact') "
+                      "[+ MSM G1 point-adds/sec under 'msm']" % L,
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (256-bit Montgomery, 32-bit limbs)", "data": "synthetic",
             "config": {"workload": ("Stark252 NTT 2^%d forward, inputs resident in HBM" % L) if world == 1 else
                                    ("Stark252 NTT, 2^%d elements per GPU x %d GPUs, %s" % (L, world, dist_mode)),
-                       "field": "Stark252", "log2n": L, "log2n_total": L + (world.bit_length() - 1 if dist_mode == "sharded" else 0),
-                       "passes": passes, "parallelism": dist_mode},
+                       "field": "Stark252", "log2n": L, "log2n_total": Lt, "passes": passes, "parallelism": dist_mode,
+                       "transport": ("library-owned RCCL communicator (lw_hip_comm_init), all-to-all = ncclSend/ncclRecv groups"
+                                     if dist_mode == "sharded" else None),
+                       "sharded_error": sharded_error},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ntt_pass_kernel", "avg_launch_ms": avg_launch_ms, "launches": launches,
@@ -181,39 +223,83 @@ def main():
             "valu": {"modmul_per_s": (n // 2) * L * args.steps * world / dt, "unit": "Montgomery products/s",
                      "peak_measured": 182.5e9 * world, "peak_source": "profiles/r01_microbench.txt (fe_mul Stark252, all CUs)",
                      "frac": (n // 2) * L * args.steps / dt / 182.5e9,
-                     "valu_busy_pmc": pmc_valu_busy("ntt_pass_kernel"),
+                     "valu_busy_pmc": pmc_counter("ntt_pass_kernel", "VALUBusy"),
                      "note": "the bound that applies: products/s against the measured product rate of the MAC pipe; "
-                             "valu_busy_pmc = rocprofv3 VALUBusy (%) from profiles/r01_pmc_summary.csv"},
+                             "valu_busy_pmc = rocprofv3 VALUBusy (%) from the newest profiles/rNN_pmc_summary.csv"},
             "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
         })
-        del t_in, t_out
+        # ---- CPU baseline on the same input + byte comparison with the timed output (rank 0, N = 1 only)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O   # checker / baseline only — never on the product path
+            gpu_out = last.cpu().numpy().view(np.uint64).reshape(n, 4)
+            t0 = time.perf_counter()
+            ref = O.evaluate_fft(O.F_STARK252, host)
+            dtc = time.perf_counter() - t0
+            ntt_exact = bool(np.array_equal(gpu_out, ref))
+            if not ntt_exact:
+                mismatch.append("NTT 2^%d output differs from the oracle" % L)
+            del gpu_out, ref
+            result["cpu_baseline"] = {"value": n / dtc, "unit": "elements/s", "cores": 1, "kind": "port",
+                                      "sample": "one Stark252 evaluate_fft of 2^%d elements (the timed GPU input), oracle/lw_oracle.c "
+                                                "(C restatement of the reference's single-threaded CPU path, twiddles regenerated "
+                                                "per call), %.1f s" % (L, dtc),
+                                      "host_cores_available": os.cpu_count()}
+            result["bit_exact"] = {"ntt": ntt_exact,
+                                   "ntt_check": "timed GPU output of the last step == oracle evaluate_fft on the same 2^%d input, "
+                                                "byte for byte" % L}
+            # context row C2: all host cores, one column per thread, as provers/stark/src/trace.rs:186-190
+            from concurrent.futures import ThreadPoolExecutor
+            thr = max(1, min(os.cpu_count() or 1, 64))
+            Lc = 20
+            cols = [rand_field_elems(1 << Lc, 0xC0150000 + k) for k in range(thr)]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(thr) as ex:
+                list(ex.map(lambda a: O.evaluate_fft(O.F_STARK252, a), cols))
+            dta = time.perf_counter() - t0
+            result["cpu_all_cores"] = {"ntt": {"value": thr * (1 << Lc) / dta, "unit": "elements/s", "cores": thr, "kind": "port",
+                                               "sample": "%d Stark252 columns of 2^%d, one oracle evaluate_fft per thread "
+                                                         "(column-parallel, trace.rs:186-190), %.1f s" % (thr, Lc, dta)}}
+            del cols
+        # ---- the drop-in call with host slices (PCIe inclusive; never the `value`)
+        if rank == 0 and world == 1 and not args.no_host_path:
+            hp = {}
+            fft.ntt(fld, host)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                fft.ntt(fld, host)
+            dth = (time.perf_counter() - t0) / 2
+            hp["ntt"] = {"ms": dth * 1e3, "elements_per_s": n / dth,
+                         "what": "lw_hip_ntt on host buffers, Stark252 2^%d: H2D + transform + D2H (%d MiB each way)" % (L, n * 32 >> 20)}
+            result["host_path"] = hp
+        del t_in, t_out, host, last
         torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ MSM leg
     if args.workload in ("msm", "all"):
-        try:
-            from bench_msm import run_msm_leg
-            result["msm"] = run_msm_leg(args, world, rank, barrier, max_over_ranks)
-        except Exception as e:   # the NTT line (the contract's `value`) must still be printed
-            result["msm"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
-
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("ntt", "all"):
-        from oracle import oracle as O   # checker / baseline only — never on the product path
-        Lc = args.cpu_log2n
-        a = rand_field_elems(1 << Lc, 0x5EED0000 + Lc)
-        t0 = time.perf_counter()
-        O.evaluate_fft(O.F_STARK252, a)
-        dtc = time.perf_counter() - t0
-        result["cpu_baseline"] = {"value": (1 << Lc) / dtc, "unit": "elements/s", "cores": 1, "kind": "port",
-                                  "sample": "one Stark252 evaluate_fft of 2^%d elements, oracle/lw_oracle.c (C restatement of the "
-                                            "reference's single-threaded CPU path, twiddles regenerated per call), %.1f s" % (Lc, dtc),
-                                  "host_cores_available": os.cpu_count()}
+        from bench_msm import run_msm_leg
+        msm_res = run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, comm_error)
+        result["msm"] = msm_res
+        be = msm_res.pop("bit_exact", None)
+        if be is not None:
+            result.setdefault("bit_exact", {}).update(be)
+            if not all(v for k, v in be.items() if k in ("msm", "msm_prefix")):
+                mismatch.append("MSM result differs from the oracle")
+        ca = msm_res.pop("cpu_all_cores", None)
+        if ca is not None:
+            result.setdefault("cpu_all_cores", {})["msm"] = ca
+        hp = msm_res.pop("host_path", None)
+        if hp is not None:
+            result.setdefault("host_path", {})["msm"] = hp
 
     if rank == 0:
         print(json.dumps(result))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
+    if mismatch:
+        print("bench.py: BIT-EXACTNESS FAILURE: " + "; ".join(mismatch), file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

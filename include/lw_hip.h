@@ -257,6 +257,12 @@ int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalar
 int lw_hip_msm_fr_device(lw_curve_t curve, const uint64_t *d_fr_elements, const void *d_points, size_t n,
                          void *out_point_host, void *hip_stream);
 
+/* Batched group law, IsGroup::operate_with (math/src/elliptic_curve/short_weierstrass/point.rs:171-207) on device
+ * buffers: d_out[j*m + i] = d_rows[i] + d_cols[j] (projective points, reference layout; the sums are generally not
+ * normalised, Z != 1).  bench.py builds its 2^24 distinct input points with it from two short runs. */
+int lw_hip_ec_add_outer_device(lw_curve_t curve, const void *d_rows, size_t m, const void *d_cols, size_t k, void *d_out,
+                               void *hip_stream);
+
 /* Fixed point set cached on the device in affine form (SURVEY 8f "next" #2, second half).  Every reference caller
  * multiplies against a structured reference string it built once: KZG commits with
  * msm(&coefficients, &srs.powers_main_group[..coefficients.len()]) (crypto/src/commitments/kzg.rs:159-163), Groth16 with

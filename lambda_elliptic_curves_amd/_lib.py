@@ -27,6 +27,7 @@ EXPORTS = [
     "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
     "lw_hip_srs_create", "lw_hip_srs_create_device", "lw_hip_srs_destroy", "lw_hip_msm_srs", "lw_hip_msm_srs_device",
     "lw_hip_msm_srs_fr",
+    "lw_hip_ec_add_outer_device",
     "lw_hip_comm_unique_id", "lw_hip_comm_init", "lw_hip_comm_shutdown", "lw_hip_comm_info",
     "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_msm_sharded_device",
 ]
@@ -123,6 +124,8 @@ def lib():
     L.lw_hip_msm_srs_fr.restype = i
     L.lw_hip_msm_srs_device.argtypes = [vp, vp, sz, vp, vp]
     L.lw_hip_msm_srs_device.restype = i
+    L.lw_hip_ec_add_outer_device.argtypes = [i, vp, sz, vp, sz, vp, vp]
+    L.lw_hip_ec_add_outer_device.restype = i
     L.lw_hip_comm_unique_id.argtypes = [vp]
     L.lw_hip_comm_unique_id.restype = i
     L.lw_hip_comm_init.argtypes = [vp, i, i]

@@ -190,6 +190,8 @@ int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points);
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
+int ec_add_outer_device(Context &c, lw_curve_t curve, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out,
+                        hipStream_t stream);
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
@@ -777,6 +779,16 @@ int lw_hip_msm(lw_curve_t curve, const uint64_t *scalars, size_t n_scalars, cons
 int lw_hip_msm_fr(lw_curve_t curve, const uint64_t *fr_elements, size_t n_scalars, const void *points, size_t n_points,
                   void *out_point) {
     return msm_host_entry(curve, fr_elements, n_scalars, points, n_points, out_point, 1);
+}
+
+// batched operate_with: out[j*m + i] = rows[i] + cols[j]
+int lw_hip_ec_add_outer_device(lw_curve_t curve, const void *d_rows, size_t m, const void *d_cols, size_t k, void *d_out, void *hip_stream) {
+    if (lw_hip_curve_point_bytes(curve) == 0) { set_error("bad curve"); return LW_ERR_BAD_ARG; }
+    if (m == 0 || k == 0) return LW_OK;
+    if (!d_rows || !d_cols || !d_out || (m >> 31) || (k >> 31)) { set_error("null buffer or oversized operand"); return LW_ERR_BAD_ARG; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    return ec_add_outer_device(en.c, curve, d_rows, (uint32_t)m, d_cols, (uint32_t)k, d_out, en.stream);
 }
 
 // ---- device-resident affine SRS (see include/lw_hip.h) ----

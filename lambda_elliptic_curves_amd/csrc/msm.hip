@@ -380,6 +380,21 @@ int msm_normalize_bn254_g2(Context &c, hipStream_t s, const void *d_in, size_t n
 int msm_normalize_bls12381_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
+int ec_add_outer_bls12381_g1(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
+int ec_add_outer_bn254_g1(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
+int ec_add_outer_bn254_g2(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
+int ec_add_outer_bls12381_g2(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
+
+int ec_add_outer_device(Context &c, lw_curve_t curve, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out,
+                        hipStream_t stream) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return ec_add_outer_bls12381_g1(c, stream, d_rows, m, d_cols, k, d_out);
+        case LW_CURVE_BN254_G1: return ec_add_outer_bn254_g1(c, stream, d_rows, m, d_cols, k, d_out);
+        case LW_CURVE_BN254_G2: return ec_add_outer_bn254_g2(c, stream, d_rows, m, d_cols, k, d_out);
+        case LW_CURVE_BLS12_381_G2: return ec_add_outer_bls12381_g2(c, stream, d_rows, m, d_cols, k, d_out);
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
 
 // affine_points: d_points are affine pairs produced by msm_normalize_device (2 field elements per row)
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,

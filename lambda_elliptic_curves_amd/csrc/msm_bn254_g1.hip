@@ -2,15 +2,5 @@
 #include "msm_core.cuh"
 
 namespace lw {
-int msm_run_bn254_g1(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine,
-                      hipEvent_t points_ready) {
-    MsmRunner<Bn254G1> r{c, s, 0};
-    r.affine = affine != 0;
-    r.points_ready = points_ready;
-    return r.run(d_scalars, d_points, n, out);
-}
-int msm_normalize_bn254_g1(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out) {
-    MsmRunner<Bn254G1> r{c, s, 0};
-    return r.normalize(d_in, n, d_out);
-}
+LW_MSM_INSTANTIATE(Bn254G1, bn254_g1)
 }  // namespace lw

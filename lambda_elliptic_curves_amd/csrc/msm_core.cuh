@@ -146,6 +146,15 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
     }
 }
 
+// Batched group law (IsGroup::operate_with, short_weierstrass/point.rs:171-207): out[j*m + i] = rows[i] + cols[j].
+// Used to synthesise large sets of distinct points from two short runs (bench inputs: P = [s0 + i*d]G + [j*m*d]G).
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void ec_add_outer_kernel(const void *rows, uint32_t m, const void *cols, uint32_t k, void *out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)m * k) return;
+    pt_st<C>(out, t, pt_add<C>(pt_ld<C>(rows, t % m), pt_ld<C>(cols, t / m)));
+}
+
 // ---------------------------------------------------------------- bucket reduce
 // in: nwin arrays of n points.  Group j of array w covers d in [j*g, (j+1)*g):
 //   A[w][j] = sum in[d],  Q[w][j] = sum (d - j*g) * in[d]     (running sum from the top, pippenger.rs:85-98)
@@ -231,6 +240,15 @@ struct MsmRunner {
         hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                            stream, d_in, (uint64_t)n, chk, d_out);
         c.prof_end("msm_to_affine_kernel", pe, stream);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+
+    int add_outer(const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) {
+        const uint64_t total = (uint64_t)m * k;
+        if (!total) return LW_OK;
+        hipLaunchKernelGGL((ec_add_outer_kernel<C>), dim3((uint32_t)((total + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, stream,
+                           d_rows, m, d_cols, k, d_out);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         return LW_OK;
     }
@@ -392,5 +410,22 @@ struct MsmRunner {
     }
 };
 
+// one translation unit per curve (they compile in parallel): the three entry points msm.hip dispatches to
+#define LW_MSM_INSTANTIATE(CURVE, SUFFIX)                                                                                        \
+    int msm_run_##SUFFIX(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine, \
+                         hipEvent_t points_ready) {                                                                                \
+        MsmRunner<CURVE> r{c, s, 0};                                                                                               \
+        r.affine = affine != 0;                                                                                                    \
+        r.points_ready = points_ready;                                                                                             \
+        return r.run(d_scalars, d_points, n, out);                                                                                 \
+    }                                                                                                                              \
+    int msm_normalize_##SUFFIX(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out) {                               \
+        MsmRunner<CURVE> r{c, s, 0};                                                                                               \
+        return r.normalize(d_in, n, d_out);                                                                                        \
+    }                                                                                                                              \
+    int ec_add_outer_##SUFFIX(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) { \
+        MsmRunner<CURVE> r{c, s, 0};                                                                                               \
+        return r.add_outer(d_rows, m, d_cols, k, d_out);                                                                           \
+    }
 
 }  // namespace lw

@@ -200,3 +200,26 @@ def test_msm_large_input_with_identity_rows():
     m = 1 << 12
     small = msm.msm(crv, sc[:m], with_id[:m])
     assert aff(oid, small) == aff(oid, O.msm(oid, sc[:m], with_id[:m]))
+
+
+@pytest.mark.parametrize("name", CURVES)
+def test_batched_group_law_outer_addition(name):
+    # lw_hip_ec_add_outer_device == IsGroup::operate_with (short_weierstrass/point.rs:171-207) pair by pair, including
+    # P + P, P + (-P) and the identity on either side
+    import ctypes as C
+    import torch
+    from lambda_elliptic_curves_amd import _lib
+    crv, oid = util.curve_pairs()[name]
+    _, pts = util.msm_case(oid, 9, 77)
+    rows = np.concatenate([pts[:5], O.ec_neutral(oid)[None, :]])
+    cols = np.stack([pts[5], pts[0], O.ec_neg(oid, pts[1]), O.ec_neutral(oid)])
+    tr, tc = torch.from_numpy(rows.view(np.int64)).cuda(), torch.from_numpy(cols.view(np.int64)).cuda()
+    out = torch.empty((len(rows) * len(cols), crv.point_words), dtype=torch.int64, device="cuda")
+    rc = _lib.lib().lw_hip_ec_add_outer_device(crv.curve, C.c_void_p(tr.data_ptr()), len(rows), C.c_void_p(tc.data_ptr()), len(cols),
+                                               C.c_void_p(out.data_ptr()), None)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    for j in range(len(cols)):
+        for i in range(len(rows)):
+            assert aff(oid, got[j * len(rows) + i]) == aff(oid, O.ec_add(oid, rows[i], cols[j])), (i, j)

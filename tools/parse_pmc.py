@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
-"""Turn two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate passes, MI355X_MICROARCH.md §HBM) into
-profiles/traffic_latest.json: HBM bytes per launch of the NTT pass kernel.
-gfx950 corrections: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream -> doubled."""
+"""Turn two rocprofv3 --pmc runs over bench.py (FETCH_SIZE, WRITE_SIZE; separate passes, MI355X_MICROARCH.md §HBM)
+into profiles/traffic_latest.json: HBM bytes per launch of the NTT pass kernel ("ntt") and HBM bytes of all MSM
+kernels of one MSM step ("msm").
+gfx950 corrections: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream -> doubled.  (The
+guide calibrates the doubling for 16-byte-per-lane streaming reads; the MSM's row gathers are 16-byte loads of 96-byte
+rows and use the same factor — stated here, not separately calibrated.)
+usage: parse_pmc.py FETCH_DIR WRITE_DIR NTT_LOG2N MSM_LOG2N MSM_STEPS_TIMED OUT.json"""
 import csv
 import glob
 import json
@@ -21,19 +25,27 @@ def per_kernel(dirpath, counter):
 
 
 def main():
-    fetch_dir, write_dir, log2n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fetch_dir, write_dir, ntt_log2n, msm_log2n, msm_steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows = {}
     for k in sorted(set(fe) | set(wr)):
         f = fe.get(k, (0, 0))[0] * 1024 * 2      # KiB -> bytes, x2 gfx950 correction
         w = wr.get(k, (0, 0))[0] * 1024
-        rows[k] = {"fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w, "launches": fe.get(k, wr.get(k))[1]}
+        rows[k.split("(")[0][:120]] = {"fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w, "launches": fe.get(k, wr.get(k))[1]}
     ntt = [v for k, v in rows.items() if "ntt_pass_kernel" in k]
     per_launch = sum(v["hbm_bytes"] * v["launches"] for v in ntt) / max(sum(v["launches"] for v in ntt), 1)
-    json.dump({"log2n": log2n, "hbm_bytes_per_launch": per_launch, "source": out, "kernels": rows,
+    # MSM: all kernels of the lw::msm_* / ec_* family; bench.py ran warm-up (2) + timed (msm_steps) MSMs in the profiled process
+    msm = {k: v for k, v in rows.items() if "lw::msm_" in k}
+    msm_total = sum(v["hbm_bytes"] * v["launches"] for v in msm.values())
+    n_msm = 2 + msm_steps
+    src = "profiles/traffic_latest.json (tools/profile_all.sh, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py)"
+    json.dump({"ntt": {"log2n": ntt_log2n, "hbm_bytes_per_launch": per_launch, "source": src},
+               "msm": {"log2n": msm_log2n, "hbm_bytes_per_launch": msm_total / n_msm, "msms_in_profile": n_msm, "source": src,
+                       "what": "HBM bytes of all MSM kernels of one MSM (sum over kernels of mean bytes x launches / MSMs run)"},
+               "kernels": rows,
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled (gfx950)"},
               open(out, "w"), indent=1)
-    print(json.dumps({"hbm_bytes_per_launch": per_launch}))
+    print(json.dumps({"ntt_hbm_bytes_per_launch": per_launch, "msm_hbm_bytes_per_msm": msm_total / n_msm}))
 
 
 if __name__ == "__main__":
