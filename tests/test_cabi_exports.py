@@ -54,3 +54,17 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_rust_shim_declares_every_symbol_and_status():
+    # rust-shim/src/ffi.rs cannot be compiled here (no Rust toolchain); at least keep it in step with the header
+    ffi = open(os.path.join(ROOT, "rust-shim", "src", "ffi.rs")).read()
+    declared = set(_declared_symbols())
+    assert set(re.findall(r"pub fn (lw_[a-z0-9_]+)\s*\(", ffi)) == declared
+    header = open(os.path.join(ROOT, "include", "lw_hip.h")).read()
+    for name, val in re.findall(r"\b(LW_(?:OK|ERR_[A-Z0-9_]+))\s*=\s*(-?\d+)", header):
+        assert re.search(r"pub const %s: c_int = %s;" % (name, val), ffi), name
+    for enum, variants in (("lw_field_t", 3), ("lw_layout_t", 4), ("lw_curve_t", 4)):
+        body = re.search(r"typedef enum \{([^}]*)\} %s;" % enum, header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        assert len(re.findall(r"=\s*\d+", body)) == variants
