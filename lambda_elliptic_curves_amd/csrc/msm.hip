@@ -48,20 +48,48 @@ void msm_launch_scalar_prep(int bn254, const void *in, void *out, uint64_t n, hi
 }
 
 // ---- bucket scatter: two-level counting sort of (point index) by key = (window, digit) ----------------------
-// Level A partitions the N*W items into coarse bins (window, high digit bits) with workgroup-local LDS histograms:
-// a workgroup counts its items per coarse bin, reserves one contiguous run per bin with a single global atomic,
-// and writes its items of that bin into the run (ranks inside the run come from LDS atomics), so global traffic is
-// runs, not scattered 4-byte stores.  Level B gives every coarse bin to one workgroup, which counting-sorts it by
-// the low 8 digit bits entirely through LDS, and emits the per-key offsets the accumulation needs.
+// Level 0 cuts every scalar into its W digits once (msm_digits_kernel: 32 B read, W x 2 B written per point), so the
+// per-window passes below read 2 bytes per point instead of the whole scalar.
+// Level A partitions the N items of ONE window (grid.y = window) into coarse bins (high digit bits): a workgroup takes
+// 16384 points, histograms them in LDS, reserves one contiguous run per bin with a single global atomic and writes its
+// items of that bin into the run (ranks from LDS atomics) — runs average 64 items (256 B).  The first version of this
+// level did all W windows in one workgroup of 1024 points: 4096 bins per workgroup, 4-item runs and 67 M contended
+// global atomics (16384 workgroups x 4096 counters); that was 6.8 of the sort's 9.5 ms at 2^24.
+// Level B gives every coarse bin to one workgroup, which counting-sorts it by the low 8 digit bits through LDS and emits
+// the per-key offsets the accumulation needs.
 constexpr uint32_t SORT_FINE_BITS = 8;
-constexpr uint32_t SORT_PTS_PER_BLOCK = 1024;   // points per level-A workgroup (x W windows items)
+constexpr uint32_t SORT_PPB = 16384;            // points per level-A workgroup (one window)
 constexpr uint32_t SORT_THREADS = 256;
-constexpr uint32_t SORT_MAX_COARSE = 4096;      // W << (c - 8) <= 16 << 8
+constexpr uint32_t SORT_MAX_COARSE = 256;       // coarse bins per window: 2^(c - 8) <= 2^8 (c <= 16)
 
 __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint64_t i, uint32_t *s) {
     const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
     uint4 a = q[0], b = q[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+
+// dig[w * n_pad + i] = digit w of scalar i (unsigned c-bit digits, pippenger.rs:76-77); rows padded with zeros to n_pad.
+// The scalar's words are walked with compile-time register indices (a runtime word index would send the eight words
+// through scratch memory: 3.2 ms instead of 0.4 at 2^24).
+__global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars, uint64_t n, uint64_t n_pad, uint32_t c, uint32_t W,
+                                                         uint16_t *dig) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < n) load_scalar_words(scalars, i, s);
+    const uint32_t t[9] = {s[6], s[7], s[4], s[5], s[2], s[3], s[0], s[1], 0u};   // 32-bit words, least significant first
+    const uint32_t mask = (1u << c) - 1;
+    uint32_t o = 0, w = 0;
+    uint16_t *out = dig + i;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint64_t v = (uint64_t)t[j] | ((uint64_t)t[j + 1] << 32);
+        while (w < W && o < 32u * (j + 1)) {
+            out[(uint64_t)w * n_pad] = (uint16_t)((uint32_t)(v >> (o - 32u * j)) & mask);
+            o += c;
+            w++;
+        }
+    }
 }
 
 // An item is (fine digit, point index): 32 bits (digit << 24 | index) when the index fits 24 bits, which halves the
@@ -78,136 +106,210 @@ template <> struct ItemPack<uint64_t> {
     static __device__ __forceinline__ uint32_t index(uint64_t it) { return (uint32_t)it; }
 };
 
-// pass A0 (count_only): coarse histogram.  pass A1: scatter packed items into the runs reserved per coarse bin.
-// A workgroup takes `ppb` points.  The scatter is bound by its 4-byte stores into W << (c - 8) runs (the count pass,
-// same loads and LDS atomics without the stores, takes a sixth of the time).
+// pass A0 (msm_coarse_count_kernel): coarse histogram.  pass A1 (msm_coarse_kernel): scatter packed items into the runs reserved per coarse bin.
+// grid = (ceil(n_pad / SORT_PPB), W); eight digits (one uint4) per load.  The scatter stages every COARSE_CHUNK points in
+// LDS in bin order and writes them out linearly, so a bin's share of the chunk (32 items on average) leaves as one
+// contiguous run; storing each item straight from its lane (4-byte stores into up to 64 runs per instruction) took 2.3 ms.
+constexpr uint32_t COARSE_CHUNK = 8192;
+constexpr int COARSE_LOADS = COARSE_CHUNK / 8 / SORT_THREADS;   // uint4 loads per work-item and chunk
+__device__ __forceinline__ uint32_t digit_of(const uint4 &v, int e) {
+    const uint32_t word = e < 2 ? v.x : e < 4 ? v.y : e < 6 ? v.z : v.w;
+    return (e & 1) ? (word >> 16) : (word & 0xffffu);
+}
+__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const uint16_t *dig, uint64_t n_pad, uint32_t c, uint32_t fine_bits,
+                                                                       uint32_t *coarse_cnt) {
+    __shared__ uint32_t h[SORT_MAX_COARSE + 1];
+    const uint32_t hb = c - fine_bits, NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
+    for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 8);
+    const uint64_t q1 = min(n_pad / 8, q0 + SORT_PPB / 8);
+    const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
+    for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
+        const uint4 v = d4[q];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t d = digit_of(v, e);
+            atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = tid; b < NB; b += SORT_THREADS)
+        if (h[b]) atomicAdd(&coarse_cnt[(w << hb) + b], h[b]);
+}
 template <class ITEM>
-__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *scalars, uint64_t n, uint32_t c, uint32_t W,
-                                                                 uint32_t fine_bits, uint32_t ppb, int count_only,
-                                                                 uint32_t *coarse_cnt, const uint32_t *coarse_off,
-                                                                 uint32_t *coarse_cursor, ITEM *items) {
-    __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
-    __shared__ uint32_t base[SORT_MAX_COARSE];
-    const uint32_t hb = c - fine_bits, CB = W << hb;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t b = tid; b < CB; b += SORT_THREADS) h[b] = 0;
+__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint16_t *dig, uint64_t n_pad, uint32_t c, uint32_t fine_bits,
+                                                                 const uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items) {
+    __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits (digit 0 contributes nothing, pippenger.rs:78)
+    __shared__ uint32_t base[SORT_MAX_COARSE];    // next free slot of this workgroup's run per bin
+    __shared__ uint32_t pre[SORT_MAX_COARSE];     // scan workspace / chunk-local exclusive offsets
+    __shared__ ITEM buf[COARSE_CHUNK];
+    __shared__ uint8_t bbin[COARSE_CHUNK];        // bin of every staged item (the packed item keeps only the fine digit)
+    const uint32_t hb = c - fine_bits, NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t bin0 = w << hb;
+    for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
-    const uint64_t p0 = (uint64_t)blockIdx.x * ppb;
-    const uint64_t p1 = min(n, p0 + ppb);
-    // zero digits go to a dummy slot so that the LDS atomics of a scalar's windows are issued back to back
-    // (no branch between them); four windows are in flight before any result is consumed
-    // the next scalar is fetched while the current one is binned (the loop is latency-bound)
-    uint32_t sn[8];
-    if (p0 + tid < p1) load_scalar_words(scalars, p0 + tid, sn);
-    for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
-        uint32_t s[8];
+    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 8);
+    const uint64_t q1 = min(n_pad / 8, q0 + SORT_PPB / 8);
+    const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
+    for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
+        const uint4 v = d4[q];
 #pragma unroll
-        for (int q = 0; q < 8; q++) s[q] = sn[q];
-        if (i + SORT_THREADS < p1) load_scalar_words(scalars, i + SORT_THREADS, sn);
-        for (uint32_t w0 = 0; w0 < W; w0 += 4) {
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t w = w0 + j;
-                const uint32_t d = w < W ? scalar_digit(s, w, c) : 0u;
-                atomicAdd(&h[d ? ((w << hb) | (d >> fine_bits)) : SORT_MAX_COARSE], 1u);
-            }
+        for (int e = 0; e < 8; e++) {
+            const uint32_t d = digit_of(v, e);
+            atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
         }
     }
     __syncthreads();
-    if (count_only) {
-        for (uint32_t b = tid; b < CB; b += SORT_THREADS)
-            if (h[b]) atomicAdd(&coarse_cnt[b], h[b]);
-        return;
-    }
-    for (uint32_t b = tid; b < CB; b += SORT_THREADS) {
-        uint32_t cnt = h[b];
-        base[b] = cnt ? coarse_off[b] + atomicAdd(&coarse_cursor[b], cnt) : 0;
-        h[b] = 0;
+    {   // one global atomic per bin reserves this workgroup's run
+        const uint32_t cnt = tid < NB ? h[tid] : 0;
+        base[tid] = cnt ? coarse_off[bin0 + tid] + atomicAdd(&coarse_cursor[bin0 + tid], cnt) : 0;
     }
     __syncthreads();
-    if (p0 + tid < p1) load_scalar_words(scalars, p0 + tid, sn);
-    for (uint64_t i = p0 + tid; i < p1; i += SORT_THREADS) {
-        uint32_t s[8];
+    const uint32_t fmask = (1u << fine_bits) - 1;
+    for (uint64_t qc = q0; qc < q1; qc += COARSE_CHUNK / 8) {
+        h[tid] = 0;
+        if (tid == 0) h[SORT_MAX_COARSE] = 0;
+        __syncthreads();
+        uint4 v[COARSE_LOADS];
+        uint32_t rk[COARSE_LOADS][8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) s[q] = sn[q];
-        if (i + SORT_THREADS < p1) load_scalar_words(scalars, i + SORT_THREADS, sn);
-        for (uint32_t w0 = 0; w0 < W; w0 += 4) {
-            uint32_t d[4], b[4], r[4];
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t w = w0 + j;
-                d[j] = w < W ? scalar_digit(s, w, c) : 0u;
-                b[j] = d[j] ? ((w << hb) | (d[j] >> fine_bits)) : SORT_MAX_COARSE;
-            }
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) r[j] = atomicAdd(&h[b[j]], 1u);
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++)
-                if (d[j]) items[base[b[j]] + r[j]] = ItemPack<ITEM>::make(d[j] & ((1u << fine_bits) - 1), i);
+        for (int l = 0; l < COARSE_LOADS; l++) {
+            const uint64_t q = qc + l * SORT_THREADS + tid;
+            v[l] = q < q1 ? d4[q] : make_uint4(0, 0, 0, 0);
         }
+#pragma unroll
+        for (int l = 0; l < COARSE_LOADS; l++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t d = digit_of(v[l], e);
+                rk[l][e] = atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
+            }
+        __syncthreads();
+        const uint32_t lcnt = h[tid];             // items of bin `tid` in this chunk (zero digits are in the dummy slot)
+        pre[tid] = lcnt;
+        __syncthreads();
+        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+            const uint32_t x = tid >= d ? pre[tid - d] : 0;
+            __syncthreads();
+            pre[tid] += x;
+            __syncthreads();
+        }
+        const uint32_t total = pre[SORT_THREADS - 1];
+        const uint32_t lex = pre[tid] - lcnt;
+        __syncthreads();
+        pre[tid] = lex;
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < COARSE_LOADS; l++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t d = digit_of(v[l], e);
+                if (d) {
+                    const uint32_t pos = pre[d >> fine_bits] + rk[l][e];
+                    buf[pos] = ItemPack<ITEM>::make(d & fmask, (qc + l * SORT_THREADS + tid) * 8 + e);
+                    bbin[pos] = (uint8_t)(d >> fine_bits);
+                }
+            }
+        __syncthreads();
+        for (uint32_t e = tid; e < total; e += SORT_THREADS) {
+            const uint32_t bin = bbin[e];
+            items[base[bin] + (e - pre[bin])] = buf[e];
+        }
+        __syncthreads();
+        base[tid] += lcnt;
+        __syncthreads();
     }
 }
 
 // pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen.
-// Both sweeps over the bin issue FINE_UNROLL independent loads per work-item before touching LDS: the kernel is bound
-// by memory latency (VALUBusy 2 %), not by the LDS atomics.
-constexpr int FINE_UNROLL = 8;
+// Sweep 1 counts the fine digits of the whole bin.  Sweep 2 takes the bin in chunks of FINE_CHUNK items: a chunk is
+// counting-sorted inside LDS first and then written out linearly, so every fine bucket receives its share of the chunk
+// as one contiguous run (32 items = 128 B on average) instead of single 4-byte stores scattered over 256 cursors (the
+// first version: 3.4x write amplification in WRITE_SIZE).
+constexpr uint32_t FINE_CHUNK = 8192;
+constexpr int FINE_PER = FINE_CHUNK / SORT_THREADS;
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, uint32_t fine_bits,
                                                                uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen) {
-    __shared__ uint32_t h[1 << SORT_FINE_BITS];
-    __shared__ uint32_t pre[1 << SORT_FINE_BITS];
+    __shared__ uint32_t h[1 << SORT_FINE_BITS];     // sweep 1: counts; sweep 2: chunk-local counts
+    __shared__ uint32_t pre[1 << SORT_FINE_BITS];   // scan workspace; sweep 2: chunk-local exclusive offsets
+    __shared__ uint32_t cur[1 << SORT_FINE_BITS];   // running global cursor per fine digit
+    __shared__ ITEM buf[FINE_CHUNK];
     const uint32_t tid = threadIdx.x, b = blockIdx.x, FB = 1u << fine_bits;
     const uint32_t i0 = coarse_off[b], i1 = coarse_off[b + 1];
-    if (tid < FB) h[tid] = 0;
+    h[tid] = 0;
     __syncthreads();
-    for (uint32_t i = i0 + tid; i < i1; i += FINE_UNROLL * SORT_THREADS) {
-        ITEM it[FINE_UNROLL];
+    for (uint32_t i = i0 + tid; i < i1; i += 8 * SORT_THREADS) {
+        ITEM it[8];
 #pragma unroll
-        for (int j = 0; j < FINE_UNROLL; j++) {
+        for (int j = 0; j < 8; j++) {
             const uint32_t k = i + j * SORT_THREADS;
             it[j] = k < i1 ? items[k] : (ITEM)0;
         }
 #pragma unroll
-        for (int j = 0; j < FINE_UNROLL; j++)
+        for (int j = 0; j < 8; j++)
             if (i + j * SORT_THREADS < i1) atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
     }
     __syncthreads();
     // exclusive scan of the FB (<= 256) counts
-    uint32_t v = tid < FB ? h[tid] : 0;
-    pre[tid] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-        uint32_t x = tid >= d ? pre[tid - d] : 0;
+    auto scan256 = [&](uint32_t v) -> uint32_t {   // returns the exclusive prefix of v over the workgroup; uses pre[]
+        pre[tid] = v;
         __syncthreads();
-        pre[tid] += x;
+        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+            const uint32_t x = tid >= d ? pre[tid - d] : 0;
+            __syncthreads();
+            pre[tid] += x;
+            __syncthreads();
+        }
+        const uint32_t r = pre[tid] - v;
         __syncthreads();
-    }
-    const uint32_t excl = pre[tid] - v;
+        return r;
+    };
+    const uint32_t v = tid < FB ? h[tid] : 0;
+    const uint32_t excl = scan256(v);
     if (tid < FB) {
         off[(b << fine_bits) | tid] = i0 + excl;
         if (v) atomicMax(maxlen, v);
     }
     if (b == gridDim.x - 1 && tid == 0) off[K] = i1;
+    cur[tid] = i0 + excl;
     __syncthreads();
-    if (tid < FB) {
-        pre[tid] = i0 + excl;   // running cursor per fine digit
-    }
-    __syncthreads();
-    for (uint32_t i = i0 + tid; i < i1; i += FINE_UNROLL * SORT_THREADS) {
-        ITEM it[FINE_UNROLL];
+    for (uint32_t c0 = i0; c0 < i1; c0 += FINE_CHUNK) {
+        const uint32_t cn = min(FINE_CHUNK, i1 - c0);
+        h[tid] = 0;
+        __syncthreads();
+        ITEM it[FINE_PER];
+        uint32_t rk[FINE_PER];
 #pragma unroll
-        for (int j = 0; j < FINE_UNROLL; j++) {
-            const uint32_t k = i + j * SORT_THREADS;
-            it[j] = k < i1 ? items[k] : (ITEM)0;
+        for (int j = 0; j < FINE_PER; j++) {
+            const uint32_t e = j * SORT_THREADS + tid;
+            it[j] = e < cn ? items[c0 + e] : (ITEM)0;
         }
 #pragma unroll
-        for (int j = 0; j < FINE_UNROLL; j++) {
-            if (i + j * SORT_THREADS < i1) {
-                uint32_t pos = atomicAdd(&pre[ItemPack<ITEM>::fine(it[j])], 1u);
-                sorted[pos] = ItemPack<ITEM>::index(it[j]);
+        for (int j = 0; j < FINE_PER; j++)
+            if (j * SORT_THREADS + tid < cn) rk[j] = atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
+        __syncthreads();
+        const uint32_t lcnt = h[tid];
+        const uint32_t lex = scan256(lcnt);
+        pre[tid] = lex;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FINE_PER; j++)
+            if (j * SORT_THREADS + tid < cn) buf[pre[ItemPack<ITEM>::fine(it[j])] + rk[j]] = it[j];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < FINE_PER; j++) {
+            const uint32_t e = j * SORT_THREADS + tid;
+            if (e < cn) {
+                const ITEM x = buf[e];
+                const uint32_t f = ItemPack<ITEM>::fine(x);
+                sorted[cur[f] + (e - pre[f])] = ItemPack<ITEM>::index(x);
             }
         }
+        __syncthreads();
+        cur[tid] += lcnt;
+        __syncthreads();
     }
 }
 
@@ -314,19 +416,24 @@ uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W) {
     const uint32_t fine = c < SORT_FINE_BITS ? c : SORT_FINE_BITS;
     return W << (c - fine);
 }
+// row length of the digit matrix: a multiple of 8 (uint4 loads) that is not a power of two, so that the W rows a wave
+// writes do not all fall on the same memory channel
+uint64_t msm_sort_padded_points(uint64_t n) { return ((n + 7) & ~(uint64_t)7) + 1032; }
 template <class ITEM>
 static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t fine, uint32_t CB,
-                          uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items, uint32_t *sorted,
-                          uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
-    const uint32_t ppb = SORT_PTS_PER_BLOCK;   // 4096 points per workgroup (longer runs per bin) measured no faster
-    const uint32_t blocks = (uint32_t)((n + ppb - 1) / ppb);
+                          uint16_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
+                          uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
+    const uint64_t n_pad = msm_sort_padded_points(n);
     hipEvent_t pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, ppb, 1, coarse_cnt,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (ITEM *)nullptr);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, s, scalars, n, n_pad, cb, W, dig);
+    c.prof_end("msm_digits_kernel", pe, s);
+    const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint16_t *)dig, n_pad, cb, fine, coarse_cnt);
     c.prof_end("msm_coarse_kernel<count>", pe, s);
     msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), dim3(blocks), dim3(SORT_THREADS), 0, s, scalars, n, cb, W, fine, ppb, 0, coarse_cnt,
+    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint16_t *)dig, n_pad, cb, fine,
                        (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
     pe = c.prof_begin(s);
@@ -334,17 +441,17 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
                        fine, sorted, off, K, maxlen);
     c.prof_end("msm_fine_kernel", pe, s);
 }
-// coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off: CB + 1; items: n*W u64; off: K + 1; maxlen: zeroed
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
+// dig: W * padded(n) u16; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off: CB + 1; items: n*W u64; off: K + 1; maxlen: zeroed
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
     const uint32_t fine = cb < SORT_FINE_BITS ? cb : SORT_FINE_BITS;
     const uint32_t CB = W << (cb - fine);
     if (n <= (1ull << 24))
-        launch_sort_t<uint32_t>(c, scalars, n, cb, W, fine, CB, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off, K,
-                                maxlen, scan_tmp, s);
+        launch_sort_t<uint32_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
+                                K, maxlen, scan_tmp, s);
     else
-        launch_sort_t<uint64_t>(c, scalars, n, cb, W, fine, CB, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
+        launch_sort_t<uint64_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
                                 scan_tmp, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
@@ -420,7 +527,11 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         // (VALUBusy 34 % and < 20 %), so the normalisation runs on a side stream beside the sort and the main stream
         // joins it just before the first accumulation launch.
         if (!c.aux_stream) {
-            if (hipStreamCreateWithFlags(&c.aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            // lowest priority: the sort on the caller's stream (2.7 ms alone) keeps its pace and the normalisation fills the
+            // issue slots it leaves; with equal priorities the sort kernels queued behind the normalisation's workgroups
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+            if (hipStreamCreateWithPriority(&c.aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&c.aux_join, hipEventDisableTiming) != hipSuccess) {
                 set_error("cannot create the MSM side stream");

@@ -1,6 +1,7 @@
 // Curve-generic part of the Pippenger MSM (see msm.hip for the schedule); instantiated once per curve in its own
 // translation unit so the four groups compile in parallel.
 #pragma once
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 #include "context.h"
@@ -14,7 +15,8 @@ constexpr int MSM_THREADS = 128;
 
 // host launchers for the curve-independent kernels (defined in msm.hip)
 uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W);
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
+uint64_t msm_sort_padded_points(uint64_t n);
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
@@ -235,7 +237,8 @@ struct MsmRunner {
         hipEvent_t pe = c.prof_begin(stream);
         // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
         // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
-        const uint32_t chk = n >= ((size_t)1 << 22) ? 128 : 32;
+        static const uint32_t chk_env = [] { const char *e = getenv("LW_HIP_MSM_CHK"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning only
+        const uint32_t chk = chk_env ? chk_env : (n >= ((size_t)1 << 22) ? 128 : 32);
         const uint64_t items = (n + chk - 1) / chk;
         hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                            stream, d_in, (uint64_t)n, chk, d_out);
@@ -305,11 +308,12 @@ struct MsmRunner {
         uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
         uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
         uint64_t *items = (uint64_t *)cv.take(8 * n * W);
+        uint16_t *dig = (uint16_t *)cv.take(2 * (size_t)W * msm_sort_padded_points(n));
         uint32_t maxlen = maxlen_hint;
         if (!dry) {
             // coarse_cnt, coarse_cursor and maxlen are adjacent carve-outs: one memset clears all three
             LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
-            msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
+            msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
                             maxlen_d, scan_tmp, stream);
             LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -74,8 +75,29 @@ int main() {
         CK(hipHostUnregister(user)); double t4 = now();
         printf("register %.1f ms, H2D %.1f, D2H %.1f, unregister %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3);
     }
+    // fresh (never touched) destination, as a new Vec / numpy.empty is: plain copy, then populate-first variants
+    for (int variant = 0; variant < 4; variant++) {
+        char *fresh = (char *)mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        double t0 = now(), tp = t0;
+        if (variant >= 1) {
+            int T = variant == 1 ? 1 : variant == 2 ? 8 : 32;
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++)
+                th.emplace_back([=] {
+                    int rc = madvise(fresh + (bytes / T) * t, bytes / T, MADV_POPULATE_WRITE);
+                    if (rc) perror("madvise");
+                });
+            for (auto &x : th) x.join();
+            tp = now();
+        }
+        CK(hipMemcpy(fresh, dev, bytes, hipMemcpyDeviceToHost));
+        double t1 = now();
+        munmap(fresh, bytes);
+        double t2 = now();
+        printf("fresh dst variant %d: populate %.1f ms, D2H %.1f ms, munmap %.1f ms\n", variant, tp - t0, t1 - tp, t2 - t1);
+    }
     { double t0 = now(); memcpy(user2, user, bytes); double t1 = now(); printf("memcpy 1 thread %.1f ms (%.1f GB/s)\n", t1 - t0, bytes / (t1 - t0) / 1e6); }
-    for (int T : {2, 4, 8, 16})
+    for (int T : {2})
         for (size_t chunk : {(size_t)4 << 20, (size_t)16 << 20}) {
             staged(user, dev, bytes, true, T, chunk);
             double t0 = now(); staged(user, dev, bytes, true, T, chunk); double t1 = now();
