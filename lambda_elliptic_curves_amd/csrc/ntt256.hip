@@ -228,6 +228,10 @@ static int ntt256_run(Context &c, int field, lw_dir_t dir, const void *d_in, voi
         p.s0 = pl.s0[i];
         p.r = pl.r[i];
         p.logC = pl.logC[i];
+        if (p.r > 8) {   // ltw[2][256] (staged twiddles) and the 17p lazy bound both need r <= 8 (ntt_kernels.cuh)
+            set_error("internal: NTT pass of %u stages", p.r);
+            return LW_ERR_BAD_ARG;
+        }
         split_steps(p.r, p);
         p.in = (const uint4 *)src;
         p.in_batch_stride = src_stride;
