@@ -49,7 +49,7 @@ __device__ __forceinline__ void bb_store_word(void *base, uint32_t idx, uint32_t
     else reinterpret_cast<uint32_t *>(base)[idx] = v;
 }
 
-template <int K, bool LAST, bool W64>
+template <int K, bool LAST, bool IN64>
 __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const void *gin, uint32_t w,
                                         uint32_t step, uint32_t t0, uint32_t base, uint32_t lgS, uint32_t hi_uniform,
                                         uint32_t hi_low, bool last_step) {
@@ -87,7 +87,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             uint32_t g;
             if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + (m << lgS) + c;
-            x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<W64>(gin, g);
+            x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<IN64>(gin, g);
         } else {
             x[j] = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
         }
@@ -122,16 +122,18 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
     }
 }
 
-template <bool LAST, bool W64>
+// IN64 / OUT64: word type of the pass's source / destination.  Only the caller's buffers hold u64 words (R = 2^64): the
+// intermediate vector between two passes is always written as u32 in the R = 2^32 domain, so a three-pass transform of
+// the u64 shapes moves (8+4) + (4+4) + (4+8) bytes per word instead of 3 x 16.
+template <bool LAST, bool IN64, bool OUT64>
 __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     __shared__ uint32_t lds[BB_TILE];
     __shared__ uint32_t ltw[LAST ? 1 : 256];
     const uint32_t tid = threadIdx.x;
     const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
     const uint32_t tile_log = r + logC;
-    const uint32_t wb = W64 ? 8 : 4;
-    const char *gin = (const char *)p.in + (uint64_t)blockIdx.y * p.in_batch_stride * wb;
-    char *gout = (char *)p.out + (uint64_t)blockIdx.y * p.out_batch_stride * wb;
+    const char *gin = (const char *)p.in + (uint64_t)blockIdx.y * p.in_batch_stride * (IN64 ? 8 : 4);
+    char *gout = (char *)p.out + (uint64_t)blockIdx.y * p.out_batch_stride * (OUT64 ? 8 : 4);
     const uint32_t b = blockIdx.x;
     const uint32_t Lw = L + lgV;      // index bits of the word array
 
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += BB_THREADS) {
-            if (k == 4) bb_item<4, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 3) bb_item<3, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) bb_item<2, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else bb_item<1, LAST, W64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (k == 4) bb_item<4, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 3) bb_item<3, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) bb_item<2, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else bb_item<1, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
         }
         t0 += k;
     }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         if (!LAST) g = base + (m << lgS) + c;
         else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
         const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
-        if (!(LW_DBG(p) & 4)) bb_store_word<W64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
+        if (!(LW_DBG(p) & 4)) bb_store_word<OUT64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
     }
 }
 
@@ -186,16 +188,15 @@ __global__ void bb_twiddle_fill_kernel(uint32_t *tw, uint32_t root, uint32_t bit
 }
 
 // x[i] *= h^i over the transform index i (all V components share the power)
-template <bool W64>
+template <bool IN64, bool OUT64>
 __global__ void bb_scale_powers_kernel(const void *in, void *out, uint32_t h, uint32_t lgV, uint64_t nwords,
                                        uint64_t in_batch_stride, uint64_t out_batch_stride) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nwords) return;
-    const uint32_t wb = W64 ? 8 : 4;
-    const char *gin = (const char *)in + (uint64_t)blockIdx.y * in_batch_stride * wb;
-    char *gout = (char *)out + (uint64_t)blockIdx.y * out_batch_stride * wb;
+    const char *gin = (const char *)in + (uint64_t)blockIdx.y * in_batch_stride * (IN64 ? 8 : 4);
+    char *gout = (char *)out + (uint64_t)blockIdx.y * out_batch_stride * (OUT64 ? 8 : 4);
     uint32_t pw = bb_pow(h, i >> lgV);
-    bb_store_word<W64>(gout, i, bb_mul(bb_load_word<W64>(gin, i), pw));
+    bb_store_word<OUT64>(gout, i, bb_mul(bb_load_word<IN64>(gin, i), pw));
 }
 
 // ---------------------------------------------------------------- host
@@ -256,13 +257,15 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
 
     const void *src = d_in;
     uint64_t src_stride = stride;
+    bool src64 = W64;   // word type of `src`: the layout's in the caller's buffers, u32 in every intermediate this function writes
     if (coset && dir == LW_DIR_FORWARD) {
         dim3 grid((uint32_t)((nwords + 255) / 256), batch);
         hipEvent_t pe = c.prof_begin(stream);
-        hipLaunchKernelGGL((bb_scale_powers_kernel<W64>), grid, dim3(256), 0, stream, d_in, c.scratch.p, h, lgV, nwords, stride, nwords);
+        hipLaunchKernelGGL((bb_scale_powers_kernel<W64, false>), grid, dim3(256), 0, stream, d_in, c.scratch.p, h, lgV, nwords, stride, nwords);
         c.prof_end("bb_scale_powers_kernel", pe, stream);
         src = c.scratch.p;
         src_stride = nwords;
+        src64 = false;
     }
     if (npass == 1 && src == d_out) {
         LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, nwords * wbytes, d_in, stride * wbytes, nwords * wbytes, batch,
@@ -309,18 +312,24 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         hipEvent_t pe = c.prof_begin(stream);
         // (a 4-columns-per-lane variant of this kernel measured no faster — the pass is bound by butterfly issue and
         // LDS exchange, not by the width of its memory instructions)
-        if (last) hipLaunchKernelGGL((bb_pass_kernel<true, W64>), grid, dim3(BB_THREADS), 0, stream, p);
-        else hipLaunchKernelGGL((bb_pass_kernel<false, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+        if (last) {
+            if (src64) hipLaunchKernelGGL((bb_pass_kernel<true, W64, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+            else hipLaunchKernelGGL((bb_pass_kernel<true, false, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+        } else {
+            if (src64) hipLaunchKernelGGL((bb_pass_kernel<false, W64, false>), grid, dim3(BB_THREADS), 0, stream, p);
+            else hipLaunchKernelGGL((bb_pass_kernel<false, false, false>), grid, dim3(BB_THREADS), 0, stream, p);
+        }
         c.prof_end(last ? "bb_pass_kernel<last>" : "bb_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;
         src_stride = p.out_batch_stride;
+        src64 = last ? W64 : false;
         s += p.r;
     }
     if (coset && dir == LW_DIR_INVERSE) {
         dim3 grid((uint32_t)((nwords + 255) / 256), batch);
         hipEvent_t pe = c.prof_begin(stream);
-        hipLaunchKernelGGL((bb_scale_powers_kernel<W64>), grid, dim3(256), 0, stream, d_out, d_out, bb_inv(h), lgV, nwords, stride, stride);
+        hipLaunchKernelGGL((bb_scale_powers_kernel<W64, W64>), grid, dim3(256), 0, stream, d_out, d_out, bb_inv(h), lgV, nwords, stride, stride);
         c.prof_end("bb_scale_powers_kernel", pe, stream);
     }
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);

@@ -16,6 +16,7 @@ def main():
     from lambda_elliptic_curves_amd import _lib, fft, msm
     from oracle import oracle as O
     from tests import util
+    from tools.synth import distinct_points
     out = {}
 
     def time_ntt(tag, fld, name, L, batch=1, inverse=False, reps=10):
@@ -47,11 +48,9 @@ def main():
     def time_msm(tag, cname, L, reps=2):
         crv, oid = util.curve_pairs()[cname]
         n = 1 << L
-        base_n = min(n, 1 << 14)
-        _, base = util.msm_case(oid, base_n, 3)
         rng = np.random.default_rng(5)
         sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2)
-        tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n // base_n, 1)
+        tp = distinct_points(crv, n)          # G, 2G, ..., nG: all distinct, Z != 1
         ts = torch.from_numpy(sc.view(np.int64)).cuda()
         msm.msm_device(crv, ts, tp, n)
         t0 = time.perf_counter()
@@ -63,14 +62,15 @@ def main():
 
     for L in (16, 20, 22, 24):
         time_msm(f"bls12_381_g1_2^{L}", "bls12_381_g1", L)
+    time_msm("bn254_g1_2^23", "bn254_g1", 23)      # BASELINE config 5: 2^26 points over 8 GPUs = 2^23 per GPU
     time_msm("bn254_g1_2^24", "bn254_g1", 24)
     time_msm("bn254_g2_2^22", "bn254_g2", 22)
+    time_msm("bn254_g2_2^23", "bn254_g2", 23)
     time_msm("bls12_381_g2_2^20", "bls12_381_g2", 20)
     # device-resident affine SRS (lw_hip_srs_*): one-off normalisation, then mixed-addition MSMs
     crv, oid = util.curve_pairs()["bls12_381_g1"]
     n = 1 << 24
-    _, base = util.msm_case(oid, 1 << 14, 3)
-    tp = torch.from_numpy(base.view(np.int64)).cuda().repeat(n >> 14, 1)
+    tp = distinct_points(crv, n)
     ts = torch.from_numpy((np.random.default_rng(5).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2)).view(np.int64)).cuda()
     t0 = time.perf_counter()
     srs = msm.Srs(crv, t_points=tp, n=n)
@@ -96,9 +96,8 @@ def main():
     out["stark252_fwd_2^24_host_buffers"] = {"ms": dt * 1e3, "elements_per_s": (1 << 24) / dt}
     print("stark252_fwd_2^24_host_buffers", out["stark252_fwd_2^24_host_buffers"], flush=True)
     crv, oid = util.curve_pairs()["bls12_381_g1"]
-    _, base = util.msm_case(oid, 1 << 14, 3)
     n = 1 << 22
-    pts = np.ascontiguousarray(np.tile(base, (n >> 14, 1)))
+    pts = distinct_points(crv, n).cpu().numpy().view(np.uint64)
     sc = np.random.default_rng(6).integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
     msm.msm(crv, sc, pts)
     t0 = time.perf_counter()
