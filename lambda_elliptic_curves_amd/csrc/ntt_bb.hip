@@ -79,16 +79,20 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
     if (LAST) hi_c = (bb_bitrev(c >> lgV, logCh) << (L - r - logCh)) | hi_low;
 
     uint32_t x[E];
+    if (step == 0) {   // branch hoisted out of the element loop: the E global loads are issued back to back
 #pragma unroll
-    for (int j = 0; j < E; j++) {
-        const uint32_t m = mbase | ((uint32_t)j << sh);
-        if (step == 0) {
+        for (int j = 0; j < E; j++) {
+            const uint32_t m = mbase | ((uint32_t)j << sh);
             // word indices fit 32 bits: two-adicity 24 (babybear.rs:29) caps a transform at 2^26 words
             uint32_t g;
             if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + (m << lgS) + c;
             x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<IN64>(gin, g);
-        } else {
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const uint32_t m = mbase | ((uint32_t)j << sh);
             x[j] = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
         }
     }

@@ -134,29 +134,35 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     }
 
     Fe<F> x[E];
+    if (step == 0) {   // branch hoisted out of the element loop: the 2E global loads are issued back to back
 #pragma unroll
-    for (int j = 0; j < E; j++) {
-        uint32_t m = mbase | ((uint32_t)j << sh);
-        uint4 q0, q1;
-        if (step == 0) {
-            uint64_t g = LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c);
+        for (int j = 0; j < E; j++) {
+            const uint32_t m = mbase | ((uint32_t)j << sh);
+            const uint64_t g = (LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c)) & p.in_mask;
+            uint4 q0, q1;
             if (LW_DBG(p) & 2) {
                 q0 = make_uint4(m, c, 1, 2);
                 q1 = make_uint4(3, 4, 5, 6);
             } else {
-                q0 = gin[2 * (g & p.in_mask)];
-                q1 = gin[2 * (g & p.in_mask) + 1];
+                q0 = gin[2 * g];
+                q1 = gin[2 * g + 1];
             }
-        } else {
-            uint32_t idx = (m << logC) | c;
-            q0 = lds[0][idx];
-            q1 = lds[1][idx];
+            x[j] = unpack_mem<F>(q0, q1);
         }
-        x[j] = unpack_mem<F>(q0, q1);
-        if (EXTRA && step == 0 && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
-            const uint64_t e = (LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c)) & p.in_mask;
-            Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, e & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, e >> p.cos_hbits));
-            x[j] = fe_mul<F>(x[j], pw);
+        if (EXTRA && p.cos_in) {   // evaluate_offset_fft: c_e * h^e, fused into the first pass's load
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const uint32_t m = mbase | ((uint32_t)j << sh);
+                const uint64_t e = (LAST ? (gbase + m) : (gbase + ((uint64_t)m << lgS) + c)) & p.in_mask;
+                Fe<F> pw = fe_mul<F>(tw_load<F>(p.cos_lo, e & ((1ull << p.cos_hbits) - 1)), tw_load<F>(p.cos_hi, e >> p.cos_hbits));
+                x[j] = fe_mul<F>(x[j], pw);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const uint32_t idx = ((mbase | ((uint32_t)j << sh)) << logC) | c;
+            x[j] = unpack_mem<F>(lds[0][idx], lds[1][idx]);
         }
     }
 
