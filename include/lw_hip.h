@@ -150,6 +150,14 @@ int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_co
  * Writes 2^order / 2 domain-field elements (host buffer, the layout's base word type).  order > 63 ->
  * LW_ERR_ORDER_TOO_LARGE; order > TWO_ADICITY -> LW_ERR_ROOT_OF_UNITY; order 0 -> nothing written. */
 int lw_hip_gen_twiddles(lw_field_t field, lw_layout_t layout, uint64_t order, int config, void *out);
+/* get_powers_of_primitive_root(order, count, config) and, with offset != NULL (config 0 only),
+ * get_powers_of_primitive_root_coset(order, count, offset) (math/src/fft/cpu/roots_of_unity.rs:13-61): out[i] =
+ * [offset *] w^(+-i), w the primitive 2^order-th root, as domain-field elements in the layout's base word (host
+ * buffer).  The bit-reversed configurations return next_power_of_two(count) entries, bit-reverse permuted, as the
+ * reference does; *out_len receives the number of entries (call with out == NULL to query it).  count 0 -> nothing.
+ * order > TWO_ADICITY -> LW_ERR_ROOT_OF_UNITY. */
+int lw_hip_gen_powers(lw_field_t field, lw_layout_t layout, uint64_t order, size_t count, int config, const void *offset_or_null,
+                      void *out, size_t *out_len);
 /* out[i] = in[bitrev(i)] over n = 2^k elements of the layout (host buffers, may alias). */
 int lw_hip_bitrev_permutation(lw_field_t field, lw_layout_t layout, const void *in, void *out, size_t n);
 

@@ -21,7 +21,7 @@ EXPORTS = [
     "lw_hip_init", "lw_hip_shutdown", "lw_hip_device_count", "lw_hip_last_error", "lw_hip_get_timings",
     "lw_hip_profile_begin", "lw_hip_profile_end",
     "lw_hip_field_elem_bytes", "lw_hip_curve_point_bytes", "lw_hip_ntt", "lw_hip_ntt_device", "lw_hip_ntt_cross_device",
-    "lw_hip_gen_twiddles", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
+    "lw_hip_gen_twiddles", "lw_hip_gen_powers", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
     "lw_hip_msm_fr", "lw_hip_msm_fr_device", "lw_groth16_h_coefficients",
     "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
@@ -90,6 +90,8 @@ def lib():
     L.lw_hip_ntt_lde_device.restype = i
     L.lw_hip_gen_twiddles.argtypes = [i, i, C.c_uint64, i, vp]
     L.lw_hip_gen_twiddles.restype = i
+    L.lw_hip_gen_powers.argtypes = [i, i, C.c_uint64, sz, i, vp, vp, C.POINTER(sz)]
+    L.lw_hip_gen_powers.restype = i
     L.lw_hip_bitrev_permutation.argtypes = [i, i, vp, vp, sz]
     L.lw_hip_bitrev_permutation.restype = i
     L.lw_polynomial_evaluate_fft.argtypes = [i, i, vp, sz, sz, sz, vp, vp, sz, C.POINTER(sz)]

@@ -209,6 +209,10 @@ int fri_layer_device(Context &c, lw_field_t field, const void *d_coeffs, uint64_
 int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d_o, uint32_t log2_gates, void *d_out, void *d_tmp,
                      hipStream_t stream);
 
+int ntt256_gen_powers(int field, uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const uint32_t *scale_words, void *d_out,
+                      hipStream_t stream);
+int ntt_bb_gen_powers(lw_layout_t layout, uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const void *scale, void *d_out,
+                      hipStream_t stream);
 int gen_twiddles_device(Context &c, lw_field_t field, lw_layout_t layout, uint32_t order, int config, void *d_out, hipStream_t stream);
 int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream);
 
@@ -463,6 +467,43 @@ int lw_hip_gen_twiddles(lw_field_t field, lw_layout_t layout, uint64_t order, in
     rc = gen_twiddles_device(c, field, layout, (uint32_t)order, config, c.host_io_b.p, 0);
     if (rc) return rc;
     LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, count * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
+// get_powers_of_primitive_root / get_powers_of_primitive_root_coset (math/src/fft/cpu/roots_of_unity.rs:13-61)
+int lw_hip_gen_powers(lw_field_t field, lw_layout_t layout, uint64_t order, size_t count, int config, const void *offset_or_null,
+                      void *out, size_t *out_len) {
+    int rc = check_field_layout(field, layout);
+    if (rc) return rc;
+    if (config < 0 || config > 3) { set_error("bad roots config %d", config); return LW_ERR_BAD_ARG; }
+    if (offset_or_null && config != 0) { set_error("the coset variant is defined for the Natural configuration only"); return LW_ERR_BAD_ARG; }
+    if (out_len) *out_len = 0;
+    if (count == 0) return LW_OK;   // roots_of_unity.rs:18-20: nothing computed, not even the root
+    if (order > field_two_adicity(field)) { set_error("no primitive 2^%llu-th root of unity in this field", (unsigned long long)order); return LW_ERR_ROOT_OF_UNITY; }
+    const bool bitrev = config >= 2, inverse = (config & 1) != 0;
+    size_t up_to = count;
+    uint32_t bits = 0;
+    if (bitrev) {   // "in bit reverse form we could need as many as (1 << count.bits()) - 1 roots": the result has next_power_of_two(count) entries
+        while (((size_t)1 << bits) < count) bits++;
+        up_to = (size_t)1 << bits;
+    }
+    if (out_len) *out_len = up_to;
+    if (!out) return LW_OK;       // size query
+    if (up_to >> 32) { set_error("%zu powers exceed the 32-bit index range", up_to); return LW_ERR_ALLOC; }
+    Entry en(nullptr);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    const size_t eb = field == LW_FIELD_BABYBEAR ? (layout == LW_LAYOUT_BABYBEAR_U32_R32 ? 4 : 8) : 32;   // domain-field words
+    if (c.host_io_b.ensure(up_to * eb)) return LW_ERR_ALLOC;
+    if (field == LW_FIELD_BABYBEAR) {
+        rc = ntt_bb_gen_powers(layout, (uint32_t)order, up_to, bitrev ? bits : 0, inverse, offset_or_null, c.host_io_b.p, 0);
+    } else {
+        uint32_t ow[8];
+        if (offset_or_null) words_from_ref(offset_or_null, ow);
+        rc = ntt256_gen_powers((int)field, (uint32_t)order, up_to, bitrev ? bits : 0, inverse, offset_or_null ? ow : nullptr, c.host_io_b.p, 0);
+    }
+    if (rc) return rc;
+    LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, up_to * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
     return LW_OK;
 }
 

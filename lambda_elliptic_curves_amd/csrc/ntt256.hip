@@ -296,6 +296,48 @@ const uint4 *ntt256_twiddle_table(Context &c, int field, lw_dir_t dir, uint32_t 
     return (const uint4 *)c.tw[field][dir].buf.p;
 }
 
+// get_powers_of_primitive_root[_coset] (math/src/fft/cpu/roots_of_unity.rs:13-61) on the device: out[i] = scale * w^e(i),
+// e(i) = i or bitrev_bits(i), w the primitive 2^order-th root or its inverse; reference memory layout.
+template <class F>
+__global__ void powers_export_kernel(uint4 *out, const uint4 *lo, const uint4 *hi, uint32_t bitrev, uint32_t hbits, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t e = bitrev ? bitrev_bits((uint32_t)i, bitrev) : i;
+    const Fe<F> x = fe_mul<F>(tw_load<F>(lo, e & ((1ull << hbits) - 1)), tw_load<F>(hi, e >> hbits));
+    uint4 q0, q1;
+    pack_mem<F>(x, q0, q1);
+    out[2 * i] = q0;
+    out[2 * i + 1] = q1;
+}
+template <class F>
+static int gen_powers_t(uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const uint32_t *scale_words, void *d_out,
+                        hipStream_t stream) {
+    uint32_t bits = 0;
+    while ((1ull << bits) < count) bits++;
+    const uint32_t hbits = (bits + 1) / 2;
+    Fe<F> w = host_root_of_unity<F>(order, inverse), sc;
+    if (scale_words)
+        for (int i = 0; i < 8; i++) sc.v[i] = scale_words[i];
+    DeviceBuf lo, hi;
+    int rc = upload_power_tables<F>(w, hbits, 1ull << (bits - hbits), lo, hi, scale_words ? &sc : nullptr);
+    if (rc == LW_OK) {
+        hipLaunchKernelGGL((powers_export_kernel<F>), dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint4 *)d_out,
+                           (const uint4 *)lo.p, (const uint4 *)hi.p, bitrev, hbits, count);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+            set_error("power table kernel failed");
+            rc = LW_ERR_LAUNCH;
+        }
+    }
+    lo.release();
+    hi.release();
+    return rc;
+}
+int ntt256_gen_powers(int field, uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const uint32_t *scale_words, void *d_out,
+                      hipStream_t stream) {
+    if (field == LW_FIELD_STARK252) return gen_powers_t<Stark252>(order, count, bitrev, inverse, scale_words, d_out, stream);
+    return gen_powers_t<Fr381>(order, count, bitrev, inverse, scale_words, d_out, stream);
+}
+
 // in_log2 < log2n: d_in holds `batch` blocks of 2^in_log2 coefficients (dense), d_out 2^log2n evaluations each
 int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
                   uint64_t stride, const uint32_t *coset_words, hipStream_t stream, uint32_t in_log2) {

@@ -340,6 +340,27 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
     return LW_OK;
 }
 
+// get_powers_of_primitive_root[_coset] for the BabyBear shapes: out[i] = scale * w^e(i) in the layout's base word
+template <bool W64>
+__global__ void bb_powers_export_kernel(void *out, uint32_t root, uint32_t scale, uint32_t bitrev, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t e = bitrev ? bb_bitrev((uint32_t)i, bitrev) : i;
+    bb_store_word<W64>(out, (uint32_t)i, bb_mul(scale, bb_pow(root, e)));
+}
+int ntt_bb_gen_powers(lw_layout_t layout, uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const void *scale, void *d_out,
+                      hipStream_t stream) {
+    const bool w64 = layout != LW_LAYOUT_BABYBEAR_U32_R32;
+    const uint32_t root = bb_host_root(order, inverse);
+    const uint32_t sc = scale ? (w64 ? bb_from_r64(*(const uint64_t *)scale) : *(const uint32_t *)scale) : BabyBear::ONE;
+    dim3 grid((uint32_t)((count + 255) / 256));
+    if (w64) hipLaunchKernelGGL((bb_powers_export_kernel<true>), grid, dim3(256), 0, stream, d_out, root, sc, bitrev, count);
+    else hipLaunchKernelGGL((bb_powers_export_kernel<false>), grid, dim3(256), 0, stream, d_out, root, sc, bitrev, count);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
 const uint32_t *ntt_bb_twiddle_table(Context &c, lw_dir_t dir, uint32_t log2n, hipStream_t stream, int *rc) {
     *rc = bb_ensure_twiddles(c, dir, log2n, stream);
     return (const uint32_t *)c.tw[LW_FIELD_BABYBEAR][dir].buf.p;

@@ -100,6 +100,28 @@ def get_twiddles(field, order, config):
     return out
 
 
+def get_powers_of_primitive_root(field, n, count, config):
+    """roots_of_unity::get_powers_of_primitive_root: `count` powers of the primitive 2^n-th root (or its inverse); the
+    bit-reversed configurations return next_power_of_two(count) entries, bit-reverse permuted."""
+    return _gen_powers(field, n, count, config, None)
+
+
+def get_powers_of_primitive_root_coset(field, n, count, offset):
+    """roots_of_unity::get_powers_of_primitive_root_coset: offset * w^i, natural order."""
+    return _gen_powers(field, n, count, ROOTS_NATURAL, offset)
+
+
+def _gen_powers(field, n, count, config, offset):
+    base_words = field.words if field.layout == L.LAYOUT_U64_LIMBS_MS_FIRST else 1
+    off = _offset_arg(field, offset)
+    olen = C.c_size_t(0)
+    check(L.lib().lw_hip_gen_powers(field.field, field.layout, n, count, config, _ptr(off), None, C.byref(olen)))
+    out = np.empty((olen.value,) if base_words == 1 else (olen.value, base_words), dtype=field.dtype)
+    if olen.value:
+        check(L.lib().lw_hip_gen_powers(field.field, field.layout, n, count, config, _ptr(off), _ptr(out), C.byref(olen)))
+    return out
+
+
 def bitrev_permutation(field, data):
     """in_place_bit_reverse_permute / the CUDA seam's bitrev_permutation (returns a new array)."""
     a = _as_elems(field, data)

@@ -112,6 +112,8 @@ extern "C" {
     pub fn lw_hip_ntt_lde_device(field: Field, layout: Layout, d_coeffs: *const c_void, log2_coeffs: u32, d_out: *mut c_void,
                                  log2n: u32, batch: u32, coset_offset_or_null: *const c_void, hip_stream: *mut c_void) -> c_int;
     pub fn lw_hip_gen_twiddles(field: Field, layout: Layout, order: u64, config: c_int, out: *mut c_void) -> c_int;
+    pub fn lw_hip_gen_powers(field: Field, layout: Layout, order: u64, count: usize, config: c_int, offset_or_null: *const c_void,
+                             out: *mut c_void, out_len: *mut usize) -> c_int;
     pub fn lw_hip_bitrev_permutation(field: Field, layout: Layout, input: *const c_void, output: *mut c_void, n: usize) -> c_int;
     pub fn lw_hip_ntt_cross_device(field: Field, layout: Layout, dir: Dir, d_in: *const c_void, d_out: *mut c_void,
                                    log2n_total: u32, log2_shards: u32, j2_begin: u64, slice_len: u64, chunk_stride_elems: u64,

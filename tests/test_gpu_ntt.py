@@ -218,3 +218,28 @@ def test_full_size_2_26_round_trip_and_dc_term():
     fft.ntt_device(fld, t_out, t_out, L, inverse=True)
     torch.cuda.synchronize()
     assert torch.equal(t_out, t_in)
+
+
+@pytest.mark.parametrize("name", ["stark252", "fr381", "babybear_u32", "babybear_u64"])
+def test_get_powers_of_primitive_root_and_coset_variant(name):
+    # roots_of_unity.rs:13-61: arbitrary `count` (also past the group order), all four configurations, and the coset
+    # variant offset * w^i; the bit-reversed configurations return next_power_of_two(count) entries
+    from lambda_elliptic_curves_amd import errors, fft
+    from oracle import bigint_def as D
+    fld, oid = util.field_pairs()[name]
+    tw_oid = oid
+    for n, count in ((4, 16), (4, 40), (10, 1000), (12, 5), (0, 3), (3, 1)):
+        for cfg, ocfg in ((fft.ROOTS_NATURAL, O.ROOTS_NATURAL), (fft.ROOTS_NATURAL_INVERSED, O.ROOTS_NATURAL_INV),
+                          (fft.ROOTS_BIT_REVERSE, O.ROOTS_BITREV), (fft.ROOTS_BIT_REVERSE_INVERSED, O.ROOTS_BITREV_INV)):
+            got = fft.get_powers_of_primitive_root(fld, n, count, cfg)
+            exp = O.get_powers_of_primitive_root(tw_oid, n, count, ocfg)
+            assert got.size == exp.size and np.array_equal(got.reshape(-1), np.asarray(exp).reshape(-1)), (n, count, cfg)
+    assert fft.get_powers_of_primitive_root(fld, 5, 0, fft.ROOTS_NATURAL).size == 0
+    p = {"stark252": D.P_STARK252, "fr381": D.P_FR381}.get(name, D.P_BABYBEAR)
+    n, count, h = 9, 777, 7
+    w = D.primitive_root_of_unity(p, n)
+    exp = O.elems_to_mont(oid, [h * pow(w, i, p) % p for i in range(count)])
+    got = fft.get_powers_of_primitive_root_coset(fld, n, count, util.offset_elem(name, h))
+    assert np.array_equal(got.reshape(-1), np.asarray(exp).reshape(-1))
+    with pytest.raises(errors.RootOfUnityError):
+        fft.get_powers_of_primitive_root(fld, fld.two_adicity + 1, 4, fft.ROOTS_NATURAL)
