@@ -193,6 +193,7 @@ int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points);
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
+size_t msm_affine_bytes(lw_curve_t curve, size_t n);
 int ec_add_outer_device(Context &c, lw_curve_t curve, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out,
                         hipStream_t stream);
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
@@ -887,7 +888,7 @@ static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream
     const size_t pb = lw_hip_curve_point_bytes(curve);
     lw_srs *h = new (std::nothrow) lw_srs{curve, n, {}};
     if (!h) return LW_ERR_ALLOC;
-    if (n && h->pts.ensure(n * (pb / 3) * 2)) { delete h; return LW_ERR_ALLOC; }
+    if (n && h->pts.ensure(msm_affine_bytes(curve, n))) { delete h; return LW_ERR_ALLOC; }
     int rc = n ? msm_normalize_device(c, curve, d_points, n, h->pts.p, stream) : LW_OK;
     if (rc == LW_OK && n && hipStreamSynchronize(stream) != hipSuccess) { set_error("SRS normalisation failed"); rc = LW_ERR_LAUNCH; }
     if (rc) { h->pts.release(); delete h; return rc; }

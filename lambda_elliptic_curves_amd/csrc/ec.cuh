@@ -283,6 +283,11 @@ template <class C>
 struct AffPoint {
     typename C::B::T x, y;
 };
+// Row stride of a device-resident affine point set: the 96-byte rows of BLS12-381 G1 are padded to 128 B so that every
+// gather of the accumulation touches exactly one 128-byte line instead of 1.75 on average (the affine copy is
+// library-owned, so its layout is free); the other groups' rows (64, 128, 192 B) are already line-friendly.
+template <class C>
+constexpr size_t aff_stride() { return 2 * C::B::BYTES == 96 ? 128 : 2 * C::B::BYTES; }
 template <class C>
 LW_HD bool aff_is_identity(const AffPoint<C> &p) { return C::B::is_zero(p.x) && C::B::is_zero(p.y); }
 template <class C>

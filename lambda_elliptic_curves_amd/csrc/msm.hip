@@ -487,6 +487,20 @@ int msm_normalize_bn254_g2(Context &c, hipStream_t s, const void *d_in, size_t n
 int msm_normalize_bls12381_g2(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out);
 
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
+size_t msm_affine_bytes_bls12381_g1(size_t n);
+size_t msm_affine_bytes_bn254_g1(size_t n);
+size_t msm_affine_bytes_bn254_g2(size_t n);
+size_t msm_affine_bytes_bls12381_g2(size_t n);
+// bytes of the device-resident affine form of n points (rows may be padded, ec.cuh aff_stride)
+size_t msm_affine_bytes(lw_curve_t curve, size_t n) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_affine_bytes_bls12381_g1(n);
+        case LW_CURVE_BN254_G1: return msm_affine_bytes_bn254_g1(n);
+        case LW_CURVE_BN254_G2: return msm_affine_bytes_bn254_g2(n);
+        case LW_CURVE_BLS12_381_G2: return msm_affine_bytes_bls12381_g2(n);
+        default: return 0;
+    }
+}
 int ec_add_outer_bls12381_g1(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
 int ec_add_outer_bn254_g1(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
 int ec_add_outer_bn254_g2(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out);
@@ -521,7 +535,7 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
     hipEvent_t join = nullptr;
     if (!affine_points && auto_norm && n >= ((size_t)1 << 22)) {
-        const size_t aff_bytes = n * (lw_hip_curve_point_bytes(curve) / 3) * 2;
+        const size_t aff_bytes = msm_affine_bytes(curve, n);
         if (c.msm_affine.ensure(aff_bytes)) return LW_ERR_ALLOC;
         // The normalisation reads only the points and the bucket sort only the scalars; both are latency-bound
         // (VALUBusy 34 % and < 20 %), so the normalisation runs on a side stream beside the sort and the main stream

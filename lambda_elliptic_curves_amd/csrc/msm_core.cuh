@@ -64,8 +64,9 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
     // The gather of a point (96-288 B from a random row) is a dependent chain index -> row.  The next index is
     // fetched one addition ahead, and the next row's cache lines are touched (one dword per 128 B, discarded) before
     // the current addition starts, so the real load at the top of the next iteration hits L2.
-    constexpr int PW = (AFFINE ? 2 : 3) * C::B::BYTES / 4;   // row size in dwords
-    auto row_ptr = [&](uint32_t i) { return (const char *)pts + (size_t)i * (PW * 4); };
+    constexpr int PW = (AFFINE ? 2 : 3) * C::B::BYTES / 4;   // row payload in dwords
+    constexpr size_t ROW = AFFINE ? aff_stride<C>() : (size_t)PW * 4;
+    auto row_ptr = [&](uint32_t i) { return (const char *)pts + (size_t)i * ROW; };
     Point<C> acc = pt_identity<C>();
     uint32_t idx_next = b;
     if (b < e) {
@@ -84,8 +85,10 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
                 idx_next = index ? index[i + 1] : i + 1;
                 const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next));
                 touch0 = row[0];
-                touch1 = row[32 < PW ? 32 : 0];
-                touch2 = row[PW - 1];
+                if constexpr (!(ROW % 128 == 0 && PW * 4 <= 128)) {   // a padded 128-byte row is one line: one touch
+                    touch1 = row[32 < PW ? 32 : 0];
+                    touch2 = row[PW - 1];
+                }
             }
             if (!aff_is_identity<C>(q)) acc = pt_add_mixed<C>(acc, q);
         } else {
@@ -113,7 +116,7 @@ template <class C>
 __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, uint32_t chk, void *out) {
     using B = typename C::B;
     using T = typename B::T;
-    constexpr size_t PBY = 3 * B::BYTES, ABY = 2 * B::BYTES;
+    constexpr size_t PBY = 3 * B::BYTES, ABY = aff_stride<C>();
     // work-item t owns points t, t + S, t + 2S, ... (S = work-items in the grid): at every step of the walk the lanes
     // of a wave touch consecutive rows, so the strided runs are read and written coalesced
     const uint64_t S = (uint64_t)gridDim.x * blockDim.x;
@@ -247,6 +250,7 @@ struct MsmRunner {
         return LW_OK;
     }
 
+    static size_t affine_bytes(size_t n) { return n * aff_stride<C>(); }
     int add_outer(const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) {
         const uint64_t total = (uint64_t)m * k;
         if (!total) return LW_OK;
@@ -427,6 +431,7 @@ struct MsmRunner {
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         return r.normalize(d_in, n, d_out);                                                                                        \
     }                                                                                                                              \
+    size_t msm_affine_bytes_##SUFFIX(size_t n) { return MsmRunner<CURVE>::affine_bytes(n); }                                      \
     int ec_add_outer_##SUFFIX(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) { \
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         return r.add_outer(d_rows, m, d_cols, k, d_out);                                                                           \

@@ -2,9 +2,11 @@
 """Turn two rocprofv3 --pmc runs over bench.py (FETCH_SIZE, WRITE_SIZE; separate passes, MI355X_MICROARCH.md §HBM)
 into profiles/traffic_latest.json: HBM bytes per launch of the NTT pass kernel ("ntt") and HBM bytes of all MSM
 kernels of one MSM step ("msm").
-gfx950 corrections: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream -> doubled.  (The
-guide calibrates the doubling for 16-byte-per-lane streaming reads; the MSM's row gathers are 16-byte loads of 96-byte
-rows and use the same factor — stated here, not separately calibrated.)
+gfx950 corrections: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream -> doubled.  The
+guide calibrates that factor for 16-byte-per-lane STREAMING reads and says to calibrate other patterns on a known byte
+count: the MSM accumulation gathers one 128-byte-aligned 128-byte row per item (268 M items at 2^24 = 34.4 GB of lines
++ 1.07 GB of indices) and its raw FETCH_SIZE reads 35.5 GB, i.e. the counter is exact for whole-line gathers — so
+kernels whose name contains "msm_accumulate" take factor 1, everything else factor 2.
 usage: parse_pmc.py FETCH_DIR WRITE_DIR NTT_LOG2N MSM_LOG2N MSM_STEPS_TIMED OUT.json"""
 import csv
 import glob
@@ -29,7 +31,8 @@ def main():
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows = {}
     for k in sorted(set(fe) | set(wr)):
-        f = fe.get(k, (0, 0))[0] * 1024 * 2      # KiB -> bytes, x2 gfx950 correction
+        factor = 1 if "msm_accumulate" in k else 2      # see the module docstring
+        f = fe.get(k, (0, 0))[0] * 1024 * factor    # KiB -> bytes, gfx950 correction
         w = wr.get(k, (0, 0))[0] * 1024
         rows[k.split("(")[0][:120]] = {"fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w, "launches": fe.get(k, wr.get(k))[1]}
     ntt = [v for k, v in rows.items() if "ntt_pass_kernel" in k]
@@ -43,7 +46,7 @@ def main():
                "msm": {"log2n": msm_log2n, "hbm_bytes_per_launch": msm_total / n_msm, "msms_in_profile": n_msm, "source": src,
                        "what": "HBM bytes of all MSM kernels of one MSM (sum over kernels of mean bytes x launches / MSMs run)"},
                "kernels": rows,
-               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled (gfx950)"},
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled (gfx950 streaming reads) except for the whole-line gathers of msm_accumulate_kernel, calibrated at factor 1 on their known line count"},
               open(out, "w"), indent=1)
     print(json.dumps({"ntt_hbm_bytes_per_launch": per_launch, "msm_hbm_bytes_per_msm": msm_total / n_msm}))
 
