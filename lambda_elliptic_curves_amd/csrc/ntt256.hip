@@ -1,4 +1,5 @@
 // Host side of the 256-bit-field NTT: twiddle cache, pass planning, launches.
+#include <stdlib.h>
 #include <vector>
 #include "context.h"
 #include "ntt_kernels.cuh"
@@ -117,19 +118,43 @@ static void split_steps(uint32_t r, NttPassParams &p) {
     }
 }
 
+static bool g_ntt_wave_local = [] { const char *e = getenv("LW_HIP_NTT_WAVE_LOCAL"); return !e || atoi(e) != 0; }();   // A/B switch
 static uint32_t g_ntt_max_r = 8;
 void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
 
 template <class F, class CFG>
 static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassParams &p) {
     const bool extra = p.cos_in || p.cos_out || p.scale;
+    // Column layout with wave-local exchanges (ntt_kernels.cuh lds_slot): full-size tiles only — every register step has
+    // exactly one work-item per thread, so a column's items sit in the same wavefront in every step with the same k.
+    // The exchange before step s stays inside the wave when steps s-1 and s both walk rows fastest with the same k
+    // (last pass: from step 1; other passes: from step 2, their first step walks columns fastest for coalesced loads).
+    // Used by the LAST pass only: there it removes all three inter-step barriers and makes the per-lane twiddle fetches of
+    // a wave consecutive table entries (0.537 -> 0.506 ms at 2^24).  In the other passes rows-fastest work-items read 64
+    // different staged twiddles per wave where columns-fastest ones read 8 (broadcast over the columns), which costs more
+    // LDS bandwidth than the two barriers it saves (0.437 -> 0.461 ms): they keep the plain layout.
+    bool wl = g_ntt_wave_local && last && p.r >= 6;
+    uint32_t ws = 0;
+    for (uint32_t st = 0; st < p.nsteps && wl; st++)
+        if ((1u << (p.r + p.logC - p.k[st])) != (uint32_t)CFG::THREADS) wl = false;
+    if (wl)
+        for (uint32_t st = (last ? 1 : 2); st < p.nsteps; st++)
+            if (p.k[st] == p.k[st - 1] && (1u << (p.r - p.k[st])) <= 64u) ws |= 1u << st;
+    NttPassParams q = p;
+    q.wave_sync = ws;
+#define LW_LAUNCH_PASS(LASTV, EXTRAV)                                                                                          \
+    do {                                                                                                                       \
+        if (wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true>), grid, dim3(CFG::THREADS), 0, stream, q);    \
+        else hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false>), grid, dim3(CFG::THREADS), 0, stream, q);      \
+    } while (0)
     if (last) {
-        if (extra) hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG, true>), grid, dim3(CFG::THREADS), 0, stream, p);
-        else hipLaunchKernelGGL((ntt_pass_kernel<F, true, CFG, false>), grid, dim3(CFG::THREADS), 0, stream, p);
+        if (extra) LW_LAUNCH_PASS(true, true);
+        else LW_LAUNCH_PASS(true, false);
     } else {
-        if (extra) hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG, true>), grid, dim3(CFG::THREADS), 0, stream, p);
-        else hipLaunchKernelGGL((ntt_pass_kernel<F, false, CFG, false>), grid, dim3(CFG::THREADS), 0, stream, p);
+        if (extra) LW_LAUNCH_PASS(false, true);
+        else LW_LAUNCH_PASS(false, false);
     }
+#undef LW_LAUNCH_PASS
 }
 
 // cached two-level power tables of `base` (optionally inverted): base^e = lo[e & mask] * hi[e >> hbits]

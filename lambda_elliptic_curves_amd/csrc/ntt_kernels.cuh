@@ -57,6 +57,7 @@ struct NttPassParams {
     uint64_t in_mask;      // first pass of a low-degree extension: element g is read from in[g & in_mask] (see ntt256.hip)
     uint32_t lazy_in;      // input of this pass may be non-canonical (< 24p): a previous lazy pass wrote it
     uint32_t dbg;          // ablation builds only (-DLW_HIP_ABLATION, see LW_DBG): bit0 skip butterflies, bit1 skip global loads, bit2 skip global stores
+    uint32_t wave_sync;    // WL kernels: bit s set = the exchange before register step s stays inside a wavefront (no workgroup barrier)
     uint32_t scale;        // multiply outputs by sc (last pass of an inverse transform)
     uint32_t sc[8];
 };
@@ -93,10 +94,32 @@ __device__ __forceinline__ void pack_mem(const Fe<F> &a, uint4 &q0, uint4 &q1) {
     q1 = make_uint4(a.v[2], a.v[3], a.v[0], a.v[1]);
 }
 
+// LDS slot (16-byte units within a plane) of tile element (row m, column c).
+//   plain layout  (WL = false): rows of C columns, (m << logC) | c — work-items walk columns fastest.
+//   column layout (WL = true):  every column's 2^r rows are contiguous and work-items walk ROWS fastest, so that a
+//       column's butterflies of all stages belong to one wavefront (64 work-items x 4 elements = 256 rows) and the
+//       exchanges between register steps need no workgroup barrier.  The low four row bits are XOR-ed with row bits 4-5
+//       (into both bit pairs) and with the column, which makes every access pattern of the pass conflict-free over the
+//       64 banks, 16 lanes at a time: the steps' row sets {0-3}, {0,1,4,5}, {2-5} and the (column, row&1) sets of the
+//       coalesced global phases all map bijectively onto the four low slot bits.
+template <bool WL>
+__device__ __forceinline__ uint32_t lds_slot(uint32_t m, uint32_t c, uint32_t r, uint32_t logC) {
+    if (!WL) return (m << logC) | c;
+    const uint32_t sw = r >= 4 ? ((5u * ((m >> 4) & 3u)) ^ ((c & 7u) << 1)) : 0u;
+    return (c << r) | (m ^ sw);
+}
+// exchange through LDS between two register steps when producer and consumer lanes share a wavefront: LDS operations
+// of one wave execute in order, so only the compiler has to be kept from reordering them
+__device__ __forceinline__ void lds_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // One work-item: 2^K elements, K stages in registers.
 // EXTRA: the pass carries a coset scaling or the N^-1 factor (kept out of the plain transform's code: the last-pass
 // kernel is ~60 KiB of straight-line MAC chains and shares a 64 KiB instruction cache with its neighbour CU)
-template <class F, int K, bool LAST, int TILE, bool EXTRA>
+template <class F, int K, bool LAST, int TILE, bool EXTRA, bool WL>
 __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step, bool stage_tw) {
@@ -104,7 +127,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     const uint32_t r = p.r, logC = p.logC, L = p.L;
     const uint32_t sh = r - t0 - K;
     uint32_t c, mr;
-    if (LAST && step == 0) {           // rows fastest: global loads run along contiguous rows
+    if ((LAST && step == 0) || (WL && (LAST || step > 0))) {   // rows fastest: contiguous global rows / one column per wave
         mr = w & ((1u << (r - K)) - 1);
         c = w >> (r - K);
     } else {                           // columns fastest
@@ -161,8 +184,8 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     } else {
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            const uint32_t idx = ((mbase | ((uint32_t)j << sh)) << logC) | c;
-            x[j] = unpack_mem<F>(lds[0][idx], lds[1][idx]);
+            const uint32_t idx = lds_slot<WL>(mbase | ((uint32_t)j << sh), c, r, logC);
+            x[j] = unpack_mem<F>(lds[0][idx], lds[1][idx ^ (WL ? 1u : 0u)]);
         }
     }
 
@@ -257,16 +280,15 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
 
 #pragma unroll
     for (int j = 0; j < E; j++) {
-        uint32_t m = mbase | ((uint32_t)j << sh);
-        uint32_t idx = (m << logC) | c;
+        const uint32_t idx = lds_slot<WL>(mbase | ((uint32_t)j << sh), c, r, logC);
         uint4 q0, q1;
         pack_mem<F>(x[j], q0, q1);
         lds[0][idx] = q0;
-        lds[1][idx] = q1;
+        lds[1][idx ^ (WL ? 1u : 0u)] = q1;   // the planes are offset by one slot so that plane-interleaved reads spread too
     }
 }
 
-template <class F, bool LAST, class CFG, bool EXTRA>
+template <class F, bool LAST, class CFG, bool EXTRA, bool WL>
 __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_kernel(NttPassParams p) {
     constexpr int NTT_THREADS = CFG::THREADS;
     constexpr int NTT_KMAX = CFG::KMAX;
@@ -310,11 +332,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         const uint32_t k = p.k[step];
         const uint32_t nitems = 1u << (tile_log - k);
         const bool last_step = (step + 1 == p.nsteps);
-        if (step) __syncthreads();
+        if (step) {
+            if (WL && ((p.wave_sync >> step) & 1u)) lds_wave_sync();
+            else __syncthreads();
+        }
         for (uint32_t w = tid; w < nitems; w += NTT_THREADS) {
-            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
-            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
-            else ntt_item<F, 1, LAST, NTT_TILE, EXTRA>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            if (NTT_KMAX >= 3 && k == 3) ntt_item<F, (NTT_KMAX >= 3 ? 3 : 1), LAST, NTT_TILE, EXTRA, WL>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else if (k == 2) ntt_item<F, 2, LAST, NTT_TILE, EXTRA, WL>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
+            else ntt_item<F, 1, LAST, NTT_TILE, EXTRA, WL>(p, lds, (uint4 (*)[256])ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step, stage_inside && step == 0 && w == tid);
         }
         t0 += k;
     }
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         uint64_t g;
         if (!LAST) g = base + ((uint64_t)m << lgS) + c;
         else g = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)b << logC) + c;
-        if (!(LW_DBG(p) & 4)) gout[2 * g + plane] = lds[plane][e];
+        if (!(LW_DBG(p) & 4)) gout[2 * g + plane] = lds[plane][lds_slot<WL>(m, c, r, logC) ^ (WL ? plane : 0u)];
     }
 }
 
