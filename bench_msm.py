@@ -235,7 +235,7 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, 
     from bench import traffic_entry, pmc_counter
     traffic, traffic_src = traffic_entry("msm", L)
     # additions the device's accumulation performs: one per (point, window) item minus one per non-empty bucket
-    dev_c = min(max(L - 4, 4), 16)
+    dev_c = 8 if L < 17 else 16            # csrc/msm_core.cuh pick_window
     dev_w = (256 + dev_c - 1) // dev_c
     dev_adds = max(n * dev_w - dev_w * ((1 << dev_c) - 1), 0)
     return {

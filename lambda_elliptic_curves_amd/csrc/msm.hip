@@ -222,22 +222,42 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint16_t
     }
 }
 
-// pass B: one workgroup per coarse bin; counting sort by the fine digit; writes sorted indices, off[key], maxlen.
-// Sweep 1 counts the fine digits of the whole bin.  Sweep 2 takes the bin in chunks of FINE_CHUNK items: a chunk is
-// counting-sorted inside LDS first and then written out linearly, so every fine bucket receives its share of the chunk
-// as one contiguous run (32 items = 128 B on average) instead of single 4-byte stores scattered over 256 cursors (the
-// first version: 3.4x write amplification in WRITE_SIZE).
+// pass B: counting sort of every coarse bin by the fine digit; writes the sorted indices; the per-key offsets come from
+// a scan of the key counts.  A coarse bin is cut into sub-blocks of FINE_SUB items, one workgroup each, so a skewed
+// scalar distribution (a prover's witness is mostly 0 / 1 / small values: one key of window 0 then holds a large share of
+// all items, and every short top window puts all its items into a handful of keys) costs more workgroups, not one
+// serial workgroup walking millions of items — the round-1 kernel (one workgroup per coarse bin) took 8 ms for a 4 M-item
+// bin.  B0 counts the keys (LDS histogram per sub-block, one global atomic per non-empty key); B1 takes its sub-block in
+// chunks of FINE_CHUNK items, counting-sorts a chunk inside LDS, reserves a run per key with one global atomic and writes
+// the chunk out linearly, so every key receives its share of the chunk as one contiguous run (32 items = 128 B on
+// average for uniform scalars) instead of single 4-byte stores scattered over 256 cursors.
+constexpr uint32_t FINE_SUB = 131072;
 constexpr uint32_t FINE_CHUNK = 8192;
 constexpr int FINE_PER = FINE_CHUNK / SORT_THREADS;
+
+// sub_off[bin] = number of sub-blocks before `bin` (exclusive scan of ceil(len / FINE_SUB)); returns false past the end
+__device__ __forceinline__ bool fine_locate(const uint32_t *coarse_off, const uint32_t *sub_off, uint32_t CB, uint32_t blk,
+                                            uint32_t &bin, uint32_t &i0, uint32_t &i1) {
+    if (blk >= sub_off[CB]) return false;
+    uint32_t lo = 0, hi = CB;   // largest bin with sub_off[bin] <= blk (that bin is non-empty: sub_off[bin + 1] > blk)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sub_off[mid] <= blk) lo = mid; else hi = mid;
+    }
+    bin = lo;
+    const uint32_t b0 = coarse_off[lo], b1 = coarse_off[lo + 1];
+    i0 = b0 + (blk - sub_off[lo]) * FINE_SUB;
+    i1 = min(b1, i0 + FINE_SUB);
+    return true;
+}
+
 template <class ITEM>
-__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, uint32_t fine_bits,
-                                                               uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen) {
-    __shared__ uint32_t h[1 << SORT_FINE_BITS];     // sweep 1: counts; sweep 2: chunk-local counts
-    __shared__ uint32_t pre[1 << SORT_FINE_BITS];   // scan workspace; sweep 2: chunk-local exclusive offsets
-    __shared__ uint32_t cur[1 << SORT_FINE_BITS];   // running global cursor per fine digit
-    __shared__ ITEM buf[FINE_CHUNK];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x, FB = 1u << fine_bits;
-    const uint32_t i0 = coarse_off[b], i1 = coarse_off[b + 1];
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
+                                                                     uint32_t CB, uint32_t fine_bits, uint32_t *key_cnt) {
+    __shared__ uint32_t h[1 << SORT_FINE_BITS];
+    const uint32_t tid = threadIdx.x;
+    uint32_t bin, i0, i1;
+    if (!fine_locate(coarse_off, sub_off, CB, blockIdx.x, bin, i0, i1)) return;
     h[tid] = 0;
     __syncthreads();
     for (uint32_t i = i0 + tid; i < i1; i += 8 * SORT_THREADS) {
@@ -252,29 +272,21 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
             if (i + j * SORT_THREADS < i1) atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
     }
     __syncthreads();
-    // exclusive scan of the FB (<= 256) counts
-    auto scan256 = [&](uint32_t v) -> uint32_t {   // returns the exclusive prefix of v over the workgroup; uses pre[]
-        pre[tid] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-            const uint32_t x = tid >= d ? pre[tid - d] : 0;
-            __syncthreads();
-            pre[tid] += x;
-            __syncthreads();
-        }
-        const uint32_t r = pre[tid] - v;
-        __syncthreads();
-        return r;
-    };
-    const uint32_t v = tid < FB ? h[tid] : 0;
-    const uint32_t excl = scan256(v);
-    if (tid < FB) {
-        off[(b << fine_bits) | tid] = i0 + excl;
-        if (v) atomicMax(maxlen, v);
-    }
-    if (b == gridDim.x - 1 && tid == 0) off[K] = i1;
-    cur[tid] = i0 + excl;
-    __syncthreads();
+    if (tid < (1u << fine_bits) && h[tid]) atomicAdd(&key_cnt[(bin << fine_bits) | tid], h[tid]);
+}
+
+template <class ITEM>
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
+                                                               uint32_t CB, uint32_t fine_bits, const uint32_t *off, uint32_t *key_cursor,
+                                                               uint32_t *sorted) {
+    __shared__ uint32_t h[1 << SORT_FINE_BITS];     // chunk-local counts
+    __shared__ uint32_t pre[1 << SORT_FINE_BITS];   // scan workspace, then chunk-local exclusive offsets
+    __shared__ uint32_t run[1 << SORT_FINE_BITS];   // start of this chunk's run in `sorted`, per fine digit
+    __shared__ ITEM buf[FINE_CHUNK];
+    const uint32_t tid = threadIdx.x;
+    uint32_t bin, i0, i1;
+    if (!fine_locate(coarse_off, sub_off, CB, blockIdx.x, bin, i0, i1)) return;
+    const uint32_t key0 = bin << fine_bits;
     for (uint32_t c0 = i0; c0 < i1; c0 += FINE_CHUNK) {
         const uint32_t cn = min(FINE_CHUNK, i1 - c0);
         h[tid] = 0;
@@ -291,7 +303,17 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
             if (j * SORT_THREADS + tid < cn) rk[j] = atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
         __syncthreads();
         const uint32_t lcnt = h[tid];
-        const uint32_t lex = scan256(lcnt);
+        run[tid] = lcnt ? off[key0 + tid] + atomicAdd(&key_cursor[key0 + tid], lcnt) : 0;   // lcnt > 0 only below 2^fine_bits
+        pre[tid] = lcnt;
+        __syncthreads();
+        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+            const uint32_t x = tid >= d ? pre[tid - d] : 0;
+            __syncthreads();
+            pre[tid] += x;
+            __syncthreads();
+        }
+        const uint32_t lex = pre[tid] - lcnt;
+        __syncthreads();
         pre[tid] = lex;
         __syncthreads();
 #pragma unroll
@@ -304,23 +326,21 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
             if (e < cn) {
                 const ITEM x = buf[e];
                 const uint32_t f = ItemPack<ITEM>::fine(x);
-                sorted[cur[f] + (e - pre[f])] = ItemPack<ITEM>::index(x);
+                sorted[run[f] + (e - pre[f])] = ItemPack<ITEM>::index(x);
             }
         }
-        __syncthreads();
-        cur[tid] += lcnt;
         __syncthreads();
     }
 }
 
 // Exclusive scan over K keys in three launches (block partials -> top scan -> final).
-//   mode 0: in = counts[K]            -> out[K+1] = exclusive scan(counts)
-//   mode 1: in = segment offsets[K+1] -> out[K+1] = exclusive scan(ceil(len/CH))
+//   mode 0:         in = counts[K]            -> out[K+1] = exclusive scan(counts)
+//   mode = chunk>0: in = segment offsets[K+1] -> out[K+1] = exclusive scan(ceil(len/chunk))
 // *maxlen receives the largest count / segment length seen.
 constexpr uint32_t SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 __device__ __forceinline__ uint32_t scan_len(const uint32_t *in, uint32_t k, int mode) { return mode ? (in[k + 1] - in[k]) : in[k]; }
-__device__ __forceinline__ uint32_t scan_val(uint32_t len, int mode) { return mode ? (len + MSM_CH - 1) / MSM_CH : len; }
+__device__ __forceinline__ uint32_t scan_val(uint32_t len, uint32_t chunk) { return chunk ? (len + chunk - 1) / chunk : len; }   // chunk 0 = mode 0
 
 __global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_partial_kernel(const uint32_t *in, uint32_t K, int mode, uint32_t *bsum,
                                                                       uint32_t *bmax) {
@@ -422,7 +442,8 @@ uint64_t msm_sort_padded_points(uint64_t n) { return ((n + 7) & ~(uint64_t)7) + 
 template <class ITEM>
 static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t fine, uint32_t CB,
                           uint16_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
-                          uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
+                          uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
+                          uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
     hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, s, scalars, n, n_pad, cb, W, dig);
@@ -436,23 +457,32 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
     hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint16_t *)dig, n_pad, cb, fine,
                        (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
+    // level B: sub-blocks of the coarse bins -> key counts -> key offsets (+ the longest bucket) -> sorted index list
+    msm_launch_scan(coarse_off, sub_off, CB, (int)FINE_SUB, maxlen + 1, scan_tmp, s);
+    const uint32_t UB = CB + (uint32_t)(((uint64_t)n * W + FINE_SUB - 1) / FINE_SUB);   // >= sub_off[CB]; surplus workgroups exit
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_fine_kernel<ITEM>), dim3(CB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
-                       fine, sorted, off, K, maxlen);
+    hipLaunchKernelGGL((msm_fine_count_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
+                       (const uint32_t *)sub_off, CB, fine, key_cnt);
+    c.prof_end("msm_fine_count_kernel", pe, s);
+    msm_launch_scan(key_cnt, off, K, 0, maxlen, scan_tmp, s);
+    pe = c.prof_begin(s);
+    hipLaunchKernelGGL((msm_fine_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
+                       (const uint32_t *)sub_off, CB, fine, (const uint32_t *)off, key_cursor, sorted);
     c.prof_end("msm_fine_kernel", pe, s);
 }
-// dig: W * padded(n) u16; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off: CB + 1; items: n*W u64; off: K + 1; maxlen: zeroed
+// dig: W * padded(n) u16; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off, sub_off: CB + 1; items: n*W u64;
+// key_cnt / key_cursor: K zeroed u32 each; off: K + 1; maxlen: zeroed
 void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
-                     uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s) {
+                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
     const uint32_t fine = cb < SORT_FINE_BITS ? cb : SORT_FINE_BITS;
     const uint32_t CB = W << (cb - fine);
     if (n <= (1ull << 24))
         launch_sort_t<uint32_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
-                                K, maxlen, scan_tmp, s);
+                                K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, s);
     else
         launch_sort_t<uint64_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
-                                scan_tmp, s);
+                                scan_tmp, sub_off, key_cnt, key_cursor, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {

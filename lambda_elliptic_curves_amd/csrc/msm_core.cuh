@@ -18,7 +18,7 @@ uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W);
 uint64_t msm_sort_padded_points(uint64_t n);
 void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
-                     uint32_t *maxlen, uint32_t *scan_tmp, hipStream_t s);
+                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
 size_t msm_scan_scratch_bytes(uint32_t K);
 int msm_waves_per_simd();   // LW_HIP_MSM_WAVES (2 or 3): register budget of the accumulate kernel
@@ -217,13 +217,14 @@ struct Carver {   // bump allocator over the context workspace
     }
 };
 
+// Window width: a divisor of 256, so that all W windows are full (c = 16: W = 16; c = 8: W = 32).  With c = log2(N) - 4 a
+// short top window (256 mod c bits) put all N items of that window into a handful of keys — one coarse bin, one level-B
+// workgroup — and cost 25-35 % at 2^16..2^20; measured per size with LW_HIP_MSM_C (tools/ab_msm_sizes.py): c = 8 wins below
+// 2^17 (2^16: 2.39 ms against 3.19), c = 16 from there on (2^20: 8.0 ms; c = 15 is within 2 % but only for scalars below 2^255).
 static uint32_t pick_window(size_t n) {
-    uint32_t lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 4;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return (uint32_t)c;
+    static const int c_env = [] { const char *e = getenv("LW_HIP_MSM_C"); return e ? atoi(e) : 0; }();   // tuning only
+    if (c_env >= 4 && c_env <= 16) return (uint32_t)c_env;
+    return n < ((size_t)1 << 17) ? 8u : 16u;
 }
 
 template <class C>
@@ -307,7 +308,10 @@ struct MsmRunner {
         uint32_t *coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *maxlen_d = (uint32_t *)cv.take(256);
+        uint32_t *key_cnt = (uint32_t *)cv.take(4 * (size_t)K);        // zeroed with the counters above (contiguous)
+        uint32_t *key_cursor = (uint32_t *)cv.take(4 * (size_t)K);
         uint32_t *coarse_off = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
+        uint32_t *sub_off = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
         uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
         uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
@@ -315,10 +319,10 @@ struct MsmRunner {
         uint16_t *dig = (uint16_t *)cv.take(2 * (size_t)W * msm_sort_padded_points(n));
         uint32_t maxlen = maxlen_hint;
         if (!dry) {
-            // coarse_cnt, coarse_cursor and maxlen are adjacent carve-outs: one memset clears all three
+            // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
             LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
             msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
-                            maxlen_d, scan_tmp, stream);
+                            maxlen_d, scan_tmp, sub_off, key_cnt, key_cursor, stream);
             LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
@@ -334,7 +338,7 @@ struct MsmRunner {
             uint64_t out_bound = items_bound / MSM_CH + K;
             char *pout = (char *)cv.take(PB * out_bound);
             if (!dry) {
-                msm_launch_scan(seg, out_off, K, 1, maxlen_d, scan_tmp, stream);
+                msm_launch_scan(seg, out_off, K, (int)MSM_CH, maxlen_d, scan_tmp, stream);
                 uint32_t total = 0;
                 LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
                 LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);

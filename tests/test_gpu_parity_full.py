@@ -120,3 +120,28 @@ def test_babybear_4_columns_2_24_match_oracle(name):
         fft.ntt_device(fld, t_out, t_out, L, inverse=True, batch=B)
         torch.cuda.synchronize()
         assert torch.equal(t_out, t_in)
+
+
+@pytest.mark.parametrize("L", [20, 22])
+def test_msm_skewed_scalar_distribution_matches_oracle(L):
+    # A prover's witness is not uniform: mostly 0 / 1 / small values, some repeated constants.  Window 0 then has keys
+    # holding a large share of all items and the upper windows are nearly empty: the sort must not serialise on them
+    # (csrc/msm.hip level B cuts coarse bins into sub-blocks) and the result must still equal the oracle's.
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 1 << L
+    thr = util.host_threads()
+    scalars, points = util.msm_case(oid, n, 2600 + L, threads=thr)
+    rng = np.random.default_rng(L)
+    kind = rng.random(n)
+    small = np.zeros((n, 4), np.uint64)
+    small[:, 3] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    mid = np.zeros((n, 4), np.uint64)
+    mid[:, 3] = rng.integers(0, 1 << 16, size=n, dtype=np.uint64)
+    const = np.tile(O.int_to_limbs(0x0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef, 4), (n, 1))
+    scalars = np.where((kind < 0.6)[:, None], small, np.where((kind < 0.8)[:, None], mid, np.where((kind < 0.9)[:, None], const, scalars)))
+    scalars = np.ascontiguousarray(scalars)
+    got = msm.msm_device(crv, torch.from_numpy(scalars.view(np.int64)).cuda(), torch.from_numpy(points.view(np.int64)).cuda(), n)
+    exp = O.parallel_msm_with(oid, scalars, points, max(2, O.optimum_window_size(n)), thr)
+    assert _aff(oid, got) == _aff(oid, exp)
