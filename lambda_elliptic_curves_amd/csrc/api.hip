@@ -316,11 +316,15 @@ struct Prefault {
         for (unsigned t = 0; t < T; t++) {
             const size_t p0 = (size_t)t * per, p1 = p0 + per < pages ? p0 + per : pages;
             if (p0 >= p1) break;
-            th.emplace_back([=] {
+            try {   // nothing may propagate across the C ABI: without a helper thread the copy simply faults the pages itself
+                th.emplace_back([=] {
 #ifdef MADV_POPULATE_WRITE
-                (void)madvise((void *)(lo + p0 * page), (p1 - p0) * page, MADV_POPULATE_WRITE);   // best effort: the copy faults the rest
+                    (void)madvise((void *)(lo + p0 * page), (p1 - p0) * page, MADV_POPULATE_WRITE);   // best effort
 #endif
-            });
+                });
+            } catch (...) {
+                break;
+            }
         }
     }
     void join() {
