@@ -48,3 +48,34 @@ def test_bit_reverse_table_16(kats):
     arr = O.elems_to_mont(O.F_BABYBEAR_U32, list(range(16)))
     got = O.elems_from_mont(O.F_BABYBEAR_U32, fft.bitrev_permutation(fft.Babybear31PrimeFieldU32, arr))
     assert got == kats["bit_reverse_16"]["expected"]      # bit_reversing.rs:32-35
+
+
+def test_hip_path_reproduces_the_reference_held_stone_compat_trace_commitments(kats):
+    # reference-held roots (provers/stark/src/prover.rs:1273-1281,1659-1667) through the HIP path end to end:
+    # lw_polynomial_interpolate_fft -> lw_polynomial_evaluate_fft (blow-up, coset offset) -> lw_stark_commit_columns, and
+    # the device-resident chain lw_hip_ntt_device(inverse) -> lw_hip_ntt_lde_device -> lw_stark_commit_columns_device
+    import torch
+    from lambda_elliptic_curves_amd import fft, merkle
+    from oracle import oracle as O
+    from tests import util
+    fld, oid = util.field_pairs()["stark252"]
+    for case in kats["stone_compat_trace_commitments"]["cases"]:
+        n, blow = case["trace_length"], case["blowup_factor"]
+        off = util.offset_elem("stark252", case["coset_offset"])
+        cols_mont = [O.elems_to_mont(oid, col) for col in util.stone_compat_trace_columns(case["initial"], n)]
+        lde = [fft.evaluate_offset_fft(fld, fft.interpolate_fft(fld, c), blow, n, off) for c in cols_mont]
+        root, nodes = merkle.commit_columns(fld, np.stack(lde), bit_reverse=True, return_nodes=True)
+        assert bytes(root).hex() == case["root"], case["name"]
+        have = {bytes(x).hex() for x in np.asarray(nodes).reshape(-1, 32)}
+        for h in case["auth_path_nodes"]:
+            assert h in have, (case["name"], h)
+        # device-resident: trace columns -> coefficients -> LDE -> tree without leaving HBM
+        log_n, log_lde = n.bit_length() - 1, (n * blow).bit_length() - 1
+        t_tr = torch.from_numpy(np.concatenate(cols_mont).view(np.int64)).cuda()
+        t_co = torch.empty_like(t_tr)
+        fft.ntt_device(fld, t_tr, t_co, log_n, inverse=True, batch=2)
+        t_lde = torch.empty((2 << log_lde, 4), dtype=torch.int64, device="cuda")
+        fft.lde_device(fld, t_co, log_n, t_lde, log_lde, batch=2, offset=off)
+        t_nodes = torch.empty(((2 << log_lde) - 1) * 4, dtype=torch.int64, device="cuda")
+        root_d = merkle.commit_columns_device(fld, t_lde, 2, log_lde, t_nodes)
+        assert bytes(root_d).hex() == case["root"], case["name"] + " (device-resident)"

@@ -42,3 +42,24 @@ def test_merkle_layout_matches_reference_rules():
     assert nat[n - 1 + 3].tobytes() == O.keccak256(b"".join(cols[c, 3].astype(">u8").tobytes() for c in range(n_cols)))
     one = O.merkle_commit_columns(cols[:, :1], bit_reverse=True)
     assert one.shape == (1, 32) and one[0].tobytes() == O.keccak256(b"".join(cols[c, 0].astype(">u8").tobytes() for c in range(n_cols)))
+
+
+def test_oracle_reproduces_the_reference_held_stone_compat_trace_commitments(kats):
+    # The only vectors in the reference that pin NTT output THROUGH the Keccak Merkle tree (prover.rs:1273-1281,1659-1667):
+    # interpolate_fft -> evaluate_offset_fft (blow-up, coset 3) -> bit-reverse -> rows -> BatchedMerkleTree root.
+    import numpy as np
+    from oracle import oracle as O
+    from tests import util
+    oid = O.F_STARK252
+    for case in kats["stone_compat_trace_commitments"]["cases"]:
+        n, blow = case["trace_length"], case["blowup_factor"]
+        off = O.elems_to_mont(oid, [case["coset_offset"]])[0]
+        cols = []
+        for col in util.stone_compat_trace_columns(case["initial"], n):
+            poly = O.interpolate_fft(oid, O.elems_to_mont(oid, col))
+            cols.append(O.evaluate_fft(oid, poly, blow, n, off))
+        nodes = O.merkle_commit_columns(np.stack(cols), bit_reverse=True)
+        assert bytes(nodes[0]).hex() == case["root"], case["name"]
+        have = {bytes(x).hex() for x in nodes}
+        for h in case["auth_path_nodes"]:
+            assert h in have, (case["name"], h)

@@ -82,3 +82,17 @@ def host_threads(cap=16):
     """Worker threads for the CPU checker on this box (the GPU box gives a one-GPU job 16 cores)."""
     import os
     return max(1, min(cap, os.cpu_count() or 1))
+
+
+def stone_compat_trace_columns(initial, n):
+    """Fibonacci2ColsShifted trace (provers/stark/src/examples/fibonacci_2_cols_shifted.rs:249-265) as two columns of
+    canonical integers: col0[0] = 1, col1[0] = initial, (x, y) -> (y, x + y)."""
+    from oracle import bigint_def as D
+    p = D.P_STARK252
+    x, y = 1, initial % p
+    c0, c1 = [x], [y]
+    for _ in range(1, n):
+        x, y = y, (x + y) % p
+        c0.append(x)
+        c1.append(y)
+    return c0, c1
