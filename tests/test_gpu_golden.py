@@ -79,3 +79,26 @@ def test_hip_path_reproduces_the_reference_held_stone_compat_trace_commitments(k
         t_nodes = torch.empty(((2 << log_lde) - 1) * 4, dtype=torch.int64, device="cuda")
         root_d = merkle.commit_columns_device(fld, t_lde, 2, log_lde, t_nodes)
         assert bytes(root_d).hex() == case["root"], case["name"] + " (device-resident)"
+
+
+def test_hip_path_reproduces_the_reference_held_plonk_round_1_commitments(kats):
+    # provers/plonk/src/prover.rs:760-785 through the HIP path: lw_polynomial_interpolate_fft over BLS12-381 Fr, then the
+    # KZG commitment in its real call shape — Montgomery-form coefficients (representative() on the device) against a
+    # device-cached SRS prefix (lw_hip_srs_create + lw_hip_msm_srs_fr), and through plain lw_hip_msm as well
+    from lambda_elliptic_curves_amd import fft, msm
+    from oracle import oracle as O
+    from tests import util
+    kat = kats["plonk_round_1_commitments"]
+    fr, oid = O.F_FR381, O.C_BLS12_381_G1
+    crv = msm.BLS12381Curve
+    srs_pts = util.plonk_test_srs(oid, kat["srs_len"], kat["srs_secret"])
+    srs = msm.Srs(crv, srs_pts)
+    try:
+        for name, col in kat["columns"].items():
+            want = tuple(int(v, 16) for v in kat["expected"][name])
+            coeffs = fft.interpolate_fft(fft.FrField, O.elems_to_mont(fr, col), strip=True)   # Polynomial::new strips
+            assert O.point_to_affine_ints(oid, srs.msm_fr(coeffs)) == want, name
+            canon = O.ints_to_array(O.elems_from_mont(fr, coeffs), 4)
+            assert O.point_to_affine_ints(oid, msm.msm(crv, canon, srs_pts[:len(canon)])) == want, name
+    finally:
+        srs.close()

@@ -146,3 +146,17 @@ def test_gen_points_are_non_normalised_and_correct():
     for i in range(6):
         assert O.point_to_affine_ints(c, pts[i]) == D.BLS12_381_G1.tup(D.BLS12_381_G1.mul(5 + 3 * i, D.BLS12_381_G1.gen))
     assert O.limbs_to_int(pts[3][12:18]) != one
+
+
+def test_oracle_reproduces_the_reference_held_plonk_round_1_commitments(kats):
+    # provers/plonk/src/prover.rs:760-785: interpolate_fft over BLS12-381 Fr, then the KZG commitment = msm against the
+    # test SRS; the expected points are hard-coded in the reference's test
+    from tests import util
+    kat = kats["plonk_round_1_commitments"]
+    fr, oid = O.F_FR381, O.C_BLS12_381_G1
+    srs = util.plonk_test_srs(oid, kat["srs_len"], kat["srs_secret"])
+    for name, col in kat["columns"].items():
+        coeffs = O.interpolate_fft(fr, O.elems_to_mont(fr, col), strip=True)
+        ks = O.elems_from_mont(fr, coeffs)                      # .representative()
+        got = O.msm(oid, O.ints_to_array(ks, 4), srs[:len(ks)])
+        assert O.point_to_affine_ints(oid, got) == tuple(int(v, 16) for v in kat["expected"][name]), name

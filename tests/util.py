@@ -96,3 +96,11 @@ def stone_compat_trace_columns(initial, n):
         c0.append(x)
         c1.append(y)
     return c0, c1
+
+
+def plonk_test_srs(oid, length, secret=2):
+    """test_srs (provers/plonk/src/test_utils/utils.rs:32-44): [secret^i]G1, i < length, projective, via the oracle."""
+    from oracle import bigint_def as D
+    g = generator(oid)
+    r = D.P_FR381
+    return np.stack([O.ec_mul(oid, g, pow(secret, i, r), 4) for i in range(length)])
