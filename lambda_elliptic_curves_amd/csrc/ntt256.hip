@@ -93,9 +93,47 @@ static NttPlan plan_passes(uint32_t L, uint32_t max_r, uint32_t skip = 0) {
     const uint32_t Ls = L - skip;
     pl.npass = (int)((Ls + max_r - 1) / max_r);
     if (pl.npass < 1) pl.npass = 1;
-    uint32_t base = Ls / pl.npass, extra = Ls % pl.npass, s = skip;
+    uint32_t rr[8];
+    uint32_t base = Ls / pl.npass, extra = Ls % pl.npass;
+    for (int i = 0; i < pl.npass; i++) rr[i] = base + ((uint32_t)i < extra ? 1 : 0);
+    // From 2^16 up: the last pass (per-element twiddles, bit-reversed stores, wave-local exchanges) takes a full max_r
+    // stages and the others share the rest as evenly as possible in EVEN sizes — an odd pass ends in a radix-2 register
+    // step with two items per thread.  Measured (tools/ab_ntt_plan.py): 2^20 (7,7,6) 0.1056 -> (6,6,8) 0.1030 ms,
+    // 2^22 (8,7,7) 0.3588 -> (6,8,8) 0.3533, 2^26 (7,7,6,6) 6.45 -> (6,6,6,8) 6.19 ms; a short LAST pass is the worst
+    // choice (2^26 (8,8,8,2): 9.1 ms).
+    if (pl.npass >= 2 && Ls >= 16 && Ls > max_r) {
+        const int q = pl.npass - 1;
+        rr[q] = max_r;
+        const uint32_t R = Ls - max_r;
+        base = R / q;
+        extra = R % q;
+        for (int i = 0; i < q; i++) rr[i] = base + ((uint32_t)i >= (uint32_t)q - extra ? 1 : 0);
+        for (int i = 0; i + 1 < q; i++)
+            if ((rr[i] & 1) && (rr[i + 1] & 1) && rr[i + 1] < max_r && rr[i] > 1) {
+                rr[i]--;
+                rr[i + 1]++;
+            }
+    }
+    // tuning only: LW_HIP_NTT_PLAN="8,8,6" fixes the stages per pass for transforms whose stage count matches the sum
+    static const char *plan_env = getenv("LW_HIP_NTT_PLAN");
+    if (plan_env) {
+        uint32_t v[8], cnt = 0, sum = 0;
+        for (const char *q = plan_env; *q && cnt < 8;) {
+            v[cnt] = (uint32_t)atoi(q);
+            sum += v[cnt++];
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        bool ok = sum == Ls && cnt >= 1;
+        for (uint32_t i = 0; i < cnt && ok; i++) ok = v[i] >= 1 && v[i] <= max_r;
+        if (ok) {
+            pl.npass = (int)cnt;
+            for (uint32_t i = 0; i < cnt; i++) rr[i] = v[i];
+        }
+    }
+    uint32_t s = skip;
     for (int i = 0; i < pl.npass; i++) {
-        uint32_t r = base + ((uint32_t)i < extra ? 1 : 0);
+        const uint32_t r = rr[i];
         pl.s0[i] = s;
         pl.r[i] = r;
         uint32_t room = NTT_TILE_LOG - r;
