@@ -189,6 +189,50 @@ struct Bn254G2 {      // y^2 = x^3 + 3/(9+u)   (bn_254/twist.rs:46-61); 3b' prec
     }
 };
 
+// The BN254 twist has a generic constant (b' = 3/(9+u)), so the two multiplications by b3 = 3b' of every complete addition
+// are full Fp2 products: 12 N^2 of the 72 N^2 MACs of a mixed addition.  The curve y^2 = x^3 + (9 + u) is isomorphic to it
+// under (x, y) -> (L^2 x, L^3 y) with L^6 = (9 + u)/b' = (9 + u)^2 / 3 (a sixth power in Fp2; L from oracle-free big-integer
+// arithmetic, checked on the generator), and there b3 = 3(9 + u) costs 14 field additions.  Point sets that the library
+// normalises anyway (msm_to_affine_kernel: every MSM from 2^22 points, every lw_hip_srs_*) are mapped while they are
+// normalised (two more products per point, once), the whole Pippenger then runs on the isomorphic curve
+// (MsmRunner<Bn254G2Iso>) and the single result is mapped back.  Same group element, bit-identical output.
+struct Bn254G2Iso {
+    using B = Fp2Ops<Fp254>;
+    static constexpr int ACC_WAVES = 2;
+    LW_HD static Fe<Fp254> times9(const Fe<Fp254> &a) {
+        Fe<Fp254> a8 = fe_dbl<Fp254>(fe_dbl<Fp254>(fe_dbl<Fp254>(a)));
+        return fe_add<Fp254>(a8, a);
+    }
+    LW_HD static B::T mul_b3(const B::T &x) {   // 3 (9 + u)(x0 + x1 u) = 3 [(9 x0 - x1) + (x0 + 9 x1) u]
+        const Fe<Fp254> r0 = fe_sub<Fp254>(times9(x.c0), x.c1), r1 = fe_add<Fp254>(x.c0, times9(x.c1));
+        return B::T{fe_add<Fp254>(fe_dbl<Fp254>(r0), r0), fe_add<Fp254>(fe_dbl<Fp254>(r1), r1)};
+    }
+    // L^2, L^3 and their inverses, Montgomery form, least significant limb first
+    LW_HD static constexpr uint32_t k(int which, int comp, int i) {
+        constexpr uint32_t t[4][2][8] = {
+            {{0xf4ea760eu, 0x863358b0u, 0x8866346au, 0x5542f3eau, 0x320755ebu, 0xc1a1b0feu, 0x8db66114u, 0x26bed9dfu},
+             {0xcf5aeac5u, 0x64175e24u, 0xaab12f2eu, 0x917d0fa8u, 0x20ce7296u, 0x251213edu, 0x507803a1u, 0x0bff36bcu}},
+            {{0x26dc456du, 0x922bc93bu, 0xfc6bd081u, 0xc7fab160u, 0x6075cf91u, 0x939a58a8u, 0xa23e25e7u, 0x222afc9eu},
+             {0x8dac7c1cu, 0x8159c18bu, 0xfb52354eu, 0x1cb9ad90u, 0x26651e6fu, 0xd9c4ca12u, 0x742c0bffu, 0x1f3b4390u}},
+            {{0x628ccb76u, 0xaa1e5596u, 0x7632787du, 0xc4a592f3u, 0xd5fba75bu, 0x2ca71636u, 0x469ac37fu, 0x251b9825u},
+             {0xab22864cu, 0xc7a4b634u, 0xed37081fu, 0xe87a1ac9u, 0x83c7e14fu, 0x05a828d3u, 0xd881bdb9u, 0x0fc3a027u}},
+            {{0x521e31d6u, 0x86edc1fau, 0x9e0038bbu, 0xa29b17ecu, 0xc638e992u, 0x4f43fbe0u, 0x4677b41eu, 0x0b249a75u},
+             {0x3215c5f8u, 0x461ab99fu, 0xbd1e697du, 0x8871022eu, 0xf4fd856cu, 0x58c34f79u, 0xb7d214bdu, 0x0380d139u}}};
+        return t[which][comp][i];
+    }
+    LW_HD static B::T konst(int which) {   // 0: L^2, 1: L^3, 2: L^-2, 3: L^-3
+        B::T r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { r.c0.v[i] = k(which, 0, i); r.c1.v[i] = k(which, 1, i); }
+        return r;
+    }
+};
+// IsoOf<C>: the curve the accumulation of a NORMALISED point set runs on (C itself unless a cheaper model exists)
+template <class C> struct IsoOf { using type = C; static constexpr bool has = false; };
+template <> struct IsoOf<Bn254G2> { using type = Bn254G2Iso; static constexpr bool has = true; };
+template <class C> struct IsIso { static constexpr bool value = false; };
+template <> struct IsIso<Bn254G2Iso> { static constexpr bool value = true; };
+
 // ---------------------------------------------------------------- points
 template <class C>
 struct Point {
@@ -348,6 +392,17 @@ LW_HD Point<C> pt_to_affine(const Point<C> &p) {
     if (B::is_zero(p.z)) return pt_identity<C>();
     typename B::T zi = B::inv(p.z);
     return Point<C>{B::mul(p.x, zi), B::mul(p.y, zi), B::one()};
+}
+
+// normalised result of an MSM that ran on an isomorphic model -> coordinates of the caller's curve
+template <class C>
+LW_HD Point<C> pt_unmap_result(const Point<C> &p) {
+    if constexpr (IsIso<C>::value) {
+        if (C::B::is_zero(p.z)) return p;
+        return Point<C>{C::B::mul(p.x, C::konst(2)), C::B::mul(p.y, C::konst(3)), p.z};
+    } else {
+        return p;
+    }
 }
 
 }  // namespace lw

@@ -147,7 +147,12 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
         const T zinv = B::mul(inv, prev);         // 1 / z_i
         inv = B::mul(inv, z);                     // 1 / (running product through the previous point)
         const T x = B::load(pin + i * PBY), y = B::load(pin + i * PBY + B::BYTES);
-        aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(y, zinv)});
+        if constexpr (IsoOf<C>::has) {   // rows land on the cheaper isomorphic model: (L^2 x, L^3 y), see ec.cuh
+            using I = typename IsoOf<C>::type;
+            aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(B::mul(x, zinv), I::konst(0)), B::mul(B::mul(y, zinv), I::konst(1))});
+        } else {
+            aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(y, zinv)});
+        }
     }
 }
 
@@ -416,7 +421,7 @@ struct MsmRunner {
                 result = pt_add<C>(result, pt_load<C>(S.data() + PB * w));
             }
         }
-        result = pt_to_affine<C>(result);
+        result = pt_unmap_result<C>(pt_to_affine<C>(result));
         pt_store<C>(out_host, result);
         return LW_OK;
     }
@@ -426,6 +431,12 @@ struct MsmRunner {
 #define LW_MSM_INSTANTIATE(CURVE, SUFFIX)                                                                                        \
     int msm_run_##SUFFIX(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_points, size_t n, void *out, int affine, \
                          hipEvent_t points_ready) {                                                                                \
+        if (affine && IsoOf<CURVE>::has) {   /* normalised rows live on the isomorphic model (msm_to_affine_kernel) */           \
+            MsmRunner<typename IsoOf<CURVE>::type> ri{c, s, 0};                                                                    \
+            ri.affine = true;                                                                                                      \
+            ri.points_ready = points_ready;                                                                                        \
+            return ri.run(d_scalars, d_points, n, out);                                                                            \
+        }                                                                                                                          \
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         r.affine = affine != 0;                                                                                                    \
         r.points_ready = points_ready;                                                                                             \
