@@ -547,6 +547,16 @@ int ec_add_outer_device(Context &c, lw_curve_t curve, const void *d_rows, uint32
     }
 }
 
+// smallest input (log2 points) for which normalising first pays, per group (tools/ab_msm_curve.py, LW_HIP_MSM_NORM_MIN)
+static int msm_normalize_min_log2(lw_curve_t curve) {
+    switch (curve) {   // measured break-even (normalise + mixed additions against projective additions)
+        case LW_CURVE_BN254_G2: return 18;        // 2^20: 12.3 -> 11.2 ms, 2^21: 18.7 -> 16.6 (mixed addition on the isomorphic curve)
+        case LW_CURVE_BLS12_381_G2: return 19;    // 2^20: 24.2 -> 22.6 ms, 2^21: 37.2 -> 34.6; 2^18: 12.7 against 13.4
+        case LW_CURVE_BN254_G1: return 20;        // 2^20: 4.23 -> 4.11 ms
+        default: return 22;                       // BLS12-381 G1: 2^21 12.2 against 12.4, 2^22 and up faster
+    }
+}
+
 // affine_points: d_points are affine pairs produced by msm_normalize_device (2 field elements per row)
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points) {
@@ -564,7 +574,9 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     // it saves.  LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
     static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
     hipEvent_t join = nullptr;
-    if (!affine_points && auto_norm && n >= ((size_t)1 << 22)) {
+    static const int norm_min_env = [] { const char *e = getenv("LW_HIP_MSM_NORM_MIN"); return e ? atoi(e) : -1; }();   // tuning only
+    const int norm_min_log2 = norm_min_env >= 0 ? norm_min_env : msm_normalize_min_log2(curve);
+    if (!affine_points && auto_norm && n >= ((size_t)1 << norm_min_log2)) {
         const size_t aff_bytes = msm_affine_bytes(curve, n);
         if (c.msm_affine.ensure(aff_bytes)) return LW_ERR_ALLOC;
         // The normalisation reads only the points and the bucket sort only the scalars; both are latency-bound
