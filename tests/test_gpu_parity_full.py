@@ -45,7 +45,8 @@ def test_bls12_381_g1_msm_matches_oracle_on_distinct_points(L):
     _msm_vs_oracle("bls12_381_g1", L, 2400 + L)
 
 
-@pytest.mark.parametrize("name,L", [("bn254_g1", 22), ("bn254_g1", 23), ("bn254_g2", 22), ("bn254_g2", 23), ("bls12_381_g2", 20)])
+@pytest.mark.parametrize("name,L", [("bn254_g1", 20), ("bn254_g1", 22), ("bn254_g1", 23), ("bn254_g2", 18), ("bn254_g2", 22),
+                                    ("bn254_g2", 23), ("bls12_381_g2", 19), ("bls12_381_g2", 20)])
 def test_other_groups_msm_matches_oracle_at_sharded_per_gpu_size(name, L):
     # BASELINE config 5: BN254 G1 + G2 2^26 over 8 GPUs = 2^23 points per GPU
     _msm_vs_oracle(name, L, 2500 + L)
