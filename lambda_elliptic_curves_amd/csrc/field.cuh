@@ -321,6 +321,56 @@ LW_HD Fe<F> fe_mul_portable(const Fe<F> &a, const Fe<F> &b) {
     return reduce_once<F>(r);
 }
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+// Host build on a 64-bit machine: the same CIOS over 64-bit limbs with 128-bit products (4-5x the 32-bit loop above).
+// The host only combines <= 64 window sums per MSM and derives table seeds, but for small MSMs that fold was half the
+// call (2^10 points: 0.5 of 1.3 ms).
+#define LW_HOST_MUL64 1
+template <class F>
+inline Fe<F> fe_mul_host64(const Fe<F> &a, const Fe<F> &b) {
+    constexpr int N = F::N, M = N / 2;
+    static_assert(N % 2 == 0, "even number of 32-bit limbs");
+    typedef unsigned __int128 u128;
+    uint64_t A[M], B[M], P[M], t[M + 2];
+    for (int i = 0; i < M; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+        P[i] = (uint64_t)F::p(2 * i) | ((uint64_t)F::p(2 * i + 1) << 32);
+    }
+    for (int i = 0; i < M + 2; i++) t[i] = 0;
+    uint64_t z = (uint64_t)(0u - F::INV);        // p^-1 mod 2^32 ...
+    z *= 2 - P[0] * z;                           // ... one Newton step: p^-1 mod 2^64
+    const uint64_t inv = 0 - z;                  // -p^-1 mod 2^64
+    for (int i = 0; i < M; i++) {
+        u128 c = 0;
+        for (int j = 0; j < M; j++) {
+            c += (u128)A[j] * B[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[M];
+        t[M] = (uint64_t)c;
+        t[M + 1] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * inv;
+        c = ((u128)m * P[0] + t[0]) >> 64;
+        for (int j = 1; j < M; j++) {
+            c += (u128)m * P[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[M];
+        t[M - 1] = (uint64_t)c;
+        t[M] = t[M + 1] + (uint64_t)(c >> 64);
+    }
+    Fe<F> r;
+    for (int i = 0; i < M; i++) {
+        r.v[2 * i] = (uint32_t)t[i];
+        r.v[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    return reduce_once<F>(r);                    // t < 2p: every modulus here has a spare top bit
+}
+#endif
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LW_MAC_V(A, B) "v_mad_u64_u32 %0, vcc, " A ", " B ", %0\n\tv_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\t"
 
@@ -501,6 +551,8 @@ template <class F>
 LW_HD Fe<F> fe_mul(const Fe<F> &a, const Fe<F> &b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return fe_mul_gfx9<F>(a, b);
+#elif defined(LW_HOST_MUL64)
+    return fe_mul_host64<F>(a, b);
 #else
     return fe_mul_portable<F>(a, b);
 #endif
@@ -533,8 +585,8 @@ LW_HD Fe<F> fe_dot(const Fe<F> *const (&a)[P], const Fe<F> *const (&b)[P]) {
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return reduce_once<F>(r);
 #else
-    Fe<F> acc = fe_mul_portable<F>(reduce_once<F>(*a[0]), *b[0]);
-    for (int q = 1; q < P; q++) acc = fe_add<F>(acc, fe_mul_portable<F>(reduce_once<F>(*a[q]), *b[q]));
+    Fe<F> acc = fe_mul<F>(reduce_once<F>(*a[0]), *b[0]);
+    for (int q = 1; q < P; q++) acc = fe_add<F>(acc, fe_mul<F>(reduce_once<F>(*a[q]), *b[q]));
     return acc;
 #endif
 }

@@ -36,7 +36,25 @@ def test_product_host_limb_code_under_ubsan(tmp_path):
             c = fe_mul<F>(c, b);
             printf("%s %d\\n", n, (int)(c == a));
         }}
+        // the 64-bit host product (unsigned __int128 CIOS) against the 32-bit reference loop on pseudo-random residues
+        template <class F> int cmp64() {{
+            unsigned long long st = 0x9E3779B97F4A7C15ull;
+            int bad = 0;
+            for (int it = 0; it < 3000; it++) {{
+                Fe<F> a, b;
+                for (int i = 0; i < F::N; i++) {{
+                    st = st * 6364136223846793005ull + 1442695040888963407ull; a.v[i] = (unsigned)(st >> 32);
+                    st = st * 6364136223846793005ull + 1442695040888963407ull; b.v[i] = (unsigned)(st >> 32);
+                }}
+                a.v[F::N - 1] %= F::p(F::N - 1);   // top limb below the modulus' top limb: a, b < p
+                b.v[F::N - 1] %= F::p(F::N - 1);
+                if (it == 0) {{ for (int i = 0; i < F::N; i++) {{ a.v[i] = F::p(i); b.v[i] = F::p(i); }} a.v[0]--; b.v[0]--; }}   // (p-1)^2
+                bad += !(fe_mul<F>(a, b) == fe_mul_portable<F>(a, b));
+            }}
+            return bad;
+        }}
         int main() {{
+            printf("mul64 %d\\n", cmp64<Stark252>() + cmp64<Fr381>() + cmp64<Fp381>() + cmp64<Fp254>() + cmp64<Fr254>());
             run<Stark252>("stark"); run<Fr381>("fr381"); run<Fp381>("fp381"); run<Fp254>("fp254");
             Point<Bls12381G1> id = pt_identity<Bls12381G1>();
             Point<Bls12381G1> s = pt_add<Bls12381G1>(id, pt_dbl<Bls12381G1>(id));
@@ -53,4 +71,4 @@ def test_product_host_limb_code_under_ubsan(tmp_path):
                            "-o", str(exe), str(src)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split() == ["stark", "1", "fr381", "1", "fp381", "1", "fp254", "1", "id", "1", "bb", "1", "rf", "1"], out.stdout
+    assert out.stdout.split() == ["mul64", "0", "stark", "1", "fr381", "1", "fp381", "1", "fp254", "1", "id", "1", "bb", "1", "rf", "1"], out.stdout
