@@ -102,3 +102,48 @@ def test_hip_path_reproduces_the_reference_held_plonk_round_1_commitments(kats):
             assert O.point_to_affine_ints(oid, msm.msm(crv, canon, srs_pts[:len(canon)])) == want, name
     finally:
         srs.close()
+
+
+class _HipPlonkOps:
+    """tests/plonk_kat.py operations on the HIP path (host-buffer C ABI; KZG commit through a device-cached SRS)"""
+
+    def __init__(self, srs):
+        from lambda_elliptic_curves_amd import fft
+        from oracle import oracle as O
+        self.fft, self.O, self.fld, self.fr, self.oid, self.srs = fft, O, fft.FrField, O.F_FR381, O.C_BLS12_381_G1, srs
+
+    def _m(self, v):
+        return self.O.elems_to_mont(self.fr, v)
+
+    def interp(self, evals):
+        return self.O.elems_from_mont(self.fr, self.fft.interpolate_fft(self.fld, self._m(evals)))
+
+    def eval_offset(self, coeffs, domain_size, offset):
+        c = self._m(coeffs) if coeffs else np.zeros((0, 4), np.uint64)
+        return self.O.elems_from_mont(self.fr, self.fft.evaluate_offset_fft(self.fld, c, 1, domain_size, self._m([offset])[0]))
+
+    def interp_offset(self, evals, offset):
+        return self.O.elems_from_mont(self.fr, self.fft.interpolate_offset_fft(self.fld, self._m(evals), self._m([offset])[0]))
+
+    def commit(self, coeffs):   # kzg.rs:159-163: msm(coefficients.representative(), srs[..len]); Montgomery scalars in, prefix call
+        c = self._m(coeffs) if coeffs else np.zeros((0, 4), np.uint64)
+        return self.O.point_to_affine_ints(self.oid, self.srs.msm_fr(c))
+
+
+def test_hip_path_reproduces_the_reference_held_plonk_round_2_and_3_commitments(kats):
+    # provers/plonk/src/prover.rs:787-836 through the HIP path: interpolate_fft, sixteen evaluate_offset_fft calls on the
+    # 4n coset, interpolate_offset_fft (all BLS12-381 Fr) and seven KZG commitments, one of them of the zero polynomial
+    from lambda_elliptic_curves_amd import msm
+    from oracle import oracle as O
+    from tests import plonk_kat, util
+    fr, oid = O.F_FR381, O.C_BLS12_381_G1
+    srs = msm.Srs(msm.BLS12381Curve, util.plonk_test_srs(oid, 7, 2))
+    try:
+        omega = O.elems_from_mont(fr, [O.get_primitive_root_of_unity(fr, 2)])[0]
+        got = plonk_kat.rounds_1_to_3(_HipPlonkOps(srs), omega)
+    finally:
+        srs.close()
+    want = {k + "_1": v for k, v in kats["plonk_round_1_commitments"]["expected"].items()}
+    want.update(kats["plonk_round_2_3_commitments"]["expected"])
+    for name, v in want.items():
+        assert got[name] == (tuple(int(t, 16) for t in v) if v else None), name

@@ -160,3 +160,45 @@ def test_oracle_reproduces_the_reference_held_plonk_round_1_commitments(kats):
         ks = O.elems_from_mont(fr, coeffs)                      # .representative()
         got = O.msm(oid, O.ints_to_array(ks, 4), srs[:len(ks)])
         assert O.point_to_affine_ints(oid, got) == tuple(int(v, 16) for v in kat["expected"][name]), name
+
+
+class _OraclePlonkOps:
+    """tests/plonk_kat.py operations on the CPU oracle"""
+
+    def __init__(self, srs):
+        self.fr, self.oid, self.srs = O.F_FR381, O.C_BLS12_381_G1, srs
+
+    def _m(self, v):
+        return O.elems_to_mont(self.fr, v)
+
+    def interp(self, evals):
+        return O.elems_from_mont(self.fr, O.interpolate_fft(self.fr, self._m(evals)))
+
+    def eval_offset(self, coeffs, domain_size, offset):
+        import numpy as np
+        c = self._m(coeffs) if coeffs else np.zeros((0, 4), np.uint64)
+        return O.elems_from_mont(self.fr, O.evaluate_fft(self.fr, c, 1, domain_size, self._m([offset])[0]))
+
+    def interp_offset(self, evals, offset):
+        return O.elems_from_mont(self.fr, O.interpolate_fft(self.fr, self._m(evals), self._m([offset])[0]))
+
+    def commit(self, coeffs):
+        import numpy as np
+        ks = O.ints_to_array(coeffs, 4) if coeffs else np.zeros((0, 4), np.uint64)
+        return O.point_to_affine_ints(self.oid, O.msm(self.oid, ks, self.srs[:len(coeffs)]))
+
+
+def test_oracle_reproduces_the_reference_held_plonk_round_2_and_3_commitments(kats):
+    # provers/plonk/src/prover.rs:787-836: z_1, t_lo_1, t_mid_1 hard-coded, t_hi_1 the neutral element — pins
+    # interpolate_fft, evaluate_offset_fft on a 4x larger coset, interpolate_offset_fft over BLS12-381 Fr and the KZG MSM
+    from oracle import bigint_def as D
+    from tests import plonk_kat, util
+    fr, oid = O.F_FR381, O.C_BLS12_381_G1
+    srs = util.plonk_test_srs(oid, 7, 2)
+    omega = O.elems_from_mont(fr, [O.get_primitive_root_of_unity(fr, 2)])[0]
+    got = plonk_kat.rounds_1_to_3(_OraclePlonkOps(srs), omega)
+    want = dict(kats["plonk_round_1_commitments"]["expected"])
+    want = {k + "_1": v for k, v in want.items()}
+    want.update(kats["plonk_round_2_3_commitments"]["expected"])
+    for name, v in want.items():
+        assert got[name] == (tuple(int(t, 16) for t in v) if v else None), name
