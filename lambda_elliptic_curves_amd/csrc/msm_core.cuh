@@ -117,10 +117,13 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
     using B = typename C::B;
     using T = typename B::T;
     constexpr size_t PBY = 3 * B::BYTES, ABY = aff_stride<C>();
-    // work-item t owns points t, t + S, t + 2S, ... (S = work-items in the grid): at every step of the walk the lanes
-    // of a wave touch consecutive rows, so the strided runs are read and written coalesced
-    const uint64_t S = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // A workgroup owns a CONTIGUOUS block of blockDim * chk points and work-item t of it the points base + t, base + t + S,
+    // base + t + 2S, ... with S = blockDim: at every step of the walk the lanes of a wave touch consecutive rows (coalesced),
+    // and the whole workgroup stays inside a few MB (round 1 strode over the whole array, S = all work-items of the grid;
+    // same speed, worse locality).
+    const uint64_t S = blockDim.x;
+    const uint64_t base = (uint64_t)blockIdx.x * blockDim.x * chk;
+    const uint64_t t = base + threadIdx.x;
     if (t >= n) return;
     uint32_t cnt = 0;
     while (cnt < chk && t + (uint64_t)cnt * S < n) cnt++;
