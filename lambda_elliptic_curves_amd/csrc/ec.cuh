@@ -64,7 +64,7 @@ struct FpOps {
     LW_HD static T one() { return T::one(); }
     LW_HD static bool is_zero(const T &a) { return a.is_zero(); }
     LW_HD static bool eq(const T &a, const T &b) { return a == b; }
-    LW_HD static T inv(const T &a) { return fe_inv<F>(a); }
+    LW_HD static T inv(const T &a) { return fe_inv_fast<F>(a); }   // bounded binary GCD (field.cuh), ~7x cheaper than Fermat
     // reference memory (N/2 u64, MS limb first) <-> limbs
     LW_HD static T load(const void *p) { return fe_load<F>(p); }
     LW_HD static void store(void *p, const T &a) { fe_store<F>(p, a); }
@@ -131,7 +131,7 @@ struct Fp2Ops {
     LW_HD static bool is_zero(const T &a) { return a.c0.is_zero() && a.c1.is_zero(); }
     LW_HD static bool eq(const T &a, const T &b) { return a.c0 == b.c0 && a.c1 == b.c1; }
     LW_HD static T inv(const T &a) {
-        Fe<F> n = fe_inv<F>(fe_add<F>(fe_sqr<F>(a.c0), fe_sqr<F>(a.c1)));
+        Fe<F> n = fe_inv_fast<F>(fe_add<F>(fe_sqr<F>(a.c0), fe_sqr<F>(a.c1)));
         return T{fe_mul<F>(a.c0, n), fe_mul<F>(fe_neg<F>(a.c1), n)};
     }
     LW_HD static T load(const void *p) {

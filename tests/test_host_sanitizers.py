@@ -53,7 +53,25 @@ def test_product_host_limb_code_under_ubsan(tmp_path):
             }}
             return bad;
         }}
+        // the bounded-binary-GCD inverse against the Fermat inverse
+        template <class F> int cmpinv() {{
+            unsigned long long st = 0x243F6A8885A308D3ull;
+            int bad = 0;
+            for (int it = 0; it < 400; it++) {{
+                Fe<F> a;
+                for (int i = 0; i < F::N; i++) {{ st = st * 6364136223846793005ull + 1442695040888963407ull; a.v[i] = (unsigned)(st >> 32); }}
+                a.v[F::N - 1] %= F::p(F::N - 1);
+                if (it < 40) for (int i = 1 + it % F::N; i < F::N; i++) a.v[i] = 0;          // short values
+                if (it == 40) {{ for (int i = 0; i < F::N; i++) a.v[i] = F::p(i); a.v[0]--; }}  // p - 1
+                if (it == 41) {{ for (int i = 0; i < F::N; i++) a.v[i] = 0; a.v[0] = 1; }}      // 1
+                if (it == 42) {{ for (int i = 0; i < F::N; i++) a.v[i] = 0; }}                  // 0 -> 0
+                if (a.is_zero() && it != 42) a.v[0] = 5;
+                bad += !(fe_inv_fast<F>(a) == fe_inv<F>(a));
+            }}
+            return bad;
+        }}
         int main() {{
+            printf("inv %d\\n", cmpinv<Stark252>() + cmpinv<Fr381>() + cmpinv<Fp381>() + cmpinv<Fp254>() + cmpinv<Fr254>());
             printf("mul64 %d\\n", cmp64<Stark252>() + cmp64<Fr381>() + cmp64<Fp381>() + cmp64<Fp254>() + cmp64<Fr254>());
             run<Stark252>("stark"); run<Fr381>("fr381"); run<Fp381>("fp381"); run<Fp254>("fp254");
             Point<Bls12381G1> id = pt_identity<Bls12381G1>();
@@ -71,4 +89,4 @@ def test_product_host_limb_code_under_ubsan(tmp_path):
                            "-o", str(exe), str(src)])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split() == ["mul64", "0", "stark", "1", "fr381", "1", "fp381", "1", "fp254", "1", "id", "1", "bb", "1", "rf", "1"], out.stdout
+    assert out.stdout.split() == ["inv", "0", "mul64", "0", "stark", "1", "fr381", "1", "fp381", "1", "fp254", "1", "id", "1", "bb", "1", "rf", "1"], out.stdout
