@@ -156,6 +156,7 @@ static void split_steps(uint32_t r, NttPassParams &p) {
     }
 }
 
+static bool g_ntt_wave_local_all = [] { const char *e = getenv("LW_HIP_NTT_WAVE_LOCAL"); return e && atoi(e) == 2; }();   // A/B: also in non-last passes
 static bool g_ntt_wave_local = [] { const char *e = getenv("LW_HIP_NTT_WAVE_LOCAL"); return !e || atoi(e) != 0; }();   // A/B switch
 static uint32_t g_ntt_max_r = 8;
 void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
@@ -170,8 +171,9 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
     // Used by the LAST pass only: there it removes all three inter-step barriers and makes the per-lane twiddle fetches of
     // a wave consecutive table entries (0.537 -> 0.506 ms at 2^24).  In the other passes rows-fastest work-items read 64
     // different staged twiddles per wave where columns-fastest ones read 8 (broadcast over the columns), which costs more
-    // LDS bandwidth than the two barriers it saves (0.437 -> 0.461 ms): they keep the plain layout.
-    bool wl = g_ntt_wave_local && last && p.r >= 6;
+    // LDS bandwidth than the two barriers it saves (0.437 -> 0.461 ms); fetching them from the table instead, as the last
+    // pass does, is worse still (0.440 -> 0.478 ms, LW_HIP_NTT_WAVE_LOCAL=2): they keep the plain layout.
+    bool wl = g_ntt_wave_local && (last || g_ntt_wave_local_all) && p.r >= 6;
     uint32_t ws = 0;
     for (uint32_t st = 0; st < p.nsteps && wl; st++)
         if ((1u << (p.r + p.logC - p.k[st])) != (uint32_t)CFG::THREADS) wl = false;

@@ -149,7 +149,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     // them, so the workgroup pays one memory latency, not two, before its first butterfly.
     uint4 tq0, tq1;
     const uint32_t ti = threadIdx.x;
-    if (!LAST && stage_tw && ti + 1 < (1u << r)) {
+    if (!LAST && !WL && stage_tw && ti + 1 < (1u << r)) {
         const uint32_t t = 31 - __clz(ti + 1), xg = ti + 1 - (1u << t);
         const uint64_t g = ((uint64_t)hi_uniform << t) | xg;
         tq0 = p.tw[2 * g];
@@ -189,7 +189,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
         }
     }
 
-    if (!LAST && stage_tw) {   // uniform across the workgroup (see the kernel)
+    if (!LAST && !WL && stage_tw) {   // uniform across the workgroup (see the kernel)
         if (ti + 1 < (1u << r)) {
             ltw[0][ti] = tq0;
             ltw[1][ti] = tq1;
@@ -213,7 +213,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     auto fetch_tw = [&](int q) -> Fe<F> {
         const int u = 31 - __builtin_clz(q + 1), jt = q + 1 - (1 << u);
         Fe<F> tw;
-        if (LAST) {
+        if (LAST || WL) {   // from the table (L1/L2): per-lane twiddles would cost LDS bandwidth the exchanges need
             const uint64_t gt = ((uint64_t)hi_c << (t0 + u)) | ((uint64_t)m_high << u);
             tw = tw_load<F>(p.tw, (LW_DBG(p) & 32) ? ((gt | (uint32_t)jt) & 0xff) : (gt | (uint32_t)jt));
         } else {   // slot 2^t - 1 + x of the staged table
@@ -316,8 +316,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
 
     // twiddle staging happens inside the first register step when every thread runs it (the usual case);
     // tiles with fewer items than threads (small transforms) stage up front
-    const bool stage_inside = !LAST && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS;
-    if (!LAST && !stage_inside) {
+    const bool stage_inside = !LAST && !WL && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS;
+    if (!LAST && !WL && !stage_inside) {
         // stage t of the pass uses T[(hi << t) | x], x < 2^t, shared by every column of the tile
         for (uint32_t i = tid; i + 1 < (1u << r); i += NTT_THREADS) {
             const uint32_t t = 31 - __clz(i + 1), x = i + 1 - (1u << t);
