@@ -191,7 +191,7 @@ struct Bn254G2 {      // y^2 = x^3 + 3/(9+u)   (bn_254/twist.rs:46-61); 3b' prec
 
 // The BN254 twist has a generic constant (b' = 3/(9+u)), so the two multiplications by b3 = 3b' of every complete addition
 // are full Fp2 products: 12 N^2 of the 72 N^2 MACs of a mixed addition.  The curve y^2 = x^3 + (9 + u) is isomorphic to it
-// under (x, y) -> (L^2 x, L^3 y) with L^6 = (9 + u)/b' = (9 + u)^2 / 3 (a sixth power in Fp2; L from oracle-free big-integer
+// under (x, y) -> (L^2 x, L^3 y) with L^6 = (9 + u)/b' = (9 + u)^2 / 3 (a sixth power in Fp2; L computed with plain big-integer
 // arithmetic, checked on the generator), and there b3 = 3(9 + u) costs 14 field additions.  Point sets that the library
 // normalises anyway (msm_to_affine_kernel: every MSM from 2^22 points, every lw_hip_srs_*) are mapped while they are
 // normalised (two more products per point, once), the whole Pippenger then runs on the isomorphic curve
