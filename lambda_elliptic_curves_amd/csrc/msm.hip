@@ -71,23 +71,28 @@ __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint6
 // dig[w * n_pad + i] = digit w of scalar i (unsigned c-bit digits, pippenger.rs:76-77); rows padded with zeros to n_pad.
 // The scalar's words are walked with compile-time register indices (a runtime word index would send the eight words
 // through scratch memory: 3.2 ms instead of 0.4 at 2^24).
+constexpr uint32_t DIGITS_PER_THREAD = 8;   // points per work-item: 8192 workgroups at 2^24 instead of 65536 tiny ones
 __global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars, uint64_t n, uint64_t n_pad, uint32_t c, uint32_t W,
                                                          uint16_t *dig) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-    uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < n) load_scalar_words(scalars, i, s);
-    const uint32_t t[9] = {s[6], s[7], s[4], s[5], s[2], s[3], s[0], s[1], 0u};   // 32-bit words, least significant first
     const uint32_t mask = (1u << c) - 1;
-    uint32_t o = 0, w = 0;
-    uint16_t *out = dig + i;
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * DIGITS_PER_THREAD) + threadIdx.x;
+#pragma nounroll
+    for (uint32_t q = 0; q < DIGITS_PER_THREAD; q++) {
+        const uint64_t i = i0 + (uint64_t)q * 256;
+        if (i >= n_pad) return;
+        uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < n) load_scalar_words(scalars, i, s);
+        const uint32_t t[9] = {s[6], s[7], s[4], s[5], s[2], s[3], s[0], s[1], 0u};   // 32-bit words, least significant first
+        uint32_t o = 0, w = 0;
+        uint16_t *out = dig + i;
 #pragma unroll
-    for (uint32_t j = 0; j < 8; j++) {
-        const uint64_t v = (uint64_t)t[j] | ((uint64_t)t[j + 1] << 32);
-        while (w < W && o < 32u * (j + 1)) {
-            out[(uint64_t)w * n_pad] = (uint16_t)((uint32_t)(v >> (o - 32u * j)) & mask);
-            o += c;
-            w++;
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint64_t v = (uint64_t)t[j] | ((uint64_t)t[j + 1] << 32);
+            while (w < W && o < 32u * (j + 1)) {
+                out[(uint64_t)w * n_pad] = (uint16_t)((uint32_t)(v >> (o - 32u * j)) & mask);
+                o += c;
+                w++;
+            }
         }
     }
 }
@@ -446,7 +451,8 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
                           uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
     hipEvent_t pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 255) / 256)), dim3(256), 0, s, scalars, n, n_pad, cb, W, dig);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 256 * DIGITS_PER_THREAD - 1) / (256 * DIGITS_PER_THREAD))), dim3(256), 0, s,
+                       scalars, n, n_pad, cb, W, dig);
     c.prof_end("msm_digits_kernel", pe, s);
     const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
     pe = c.prof_begin(s);
