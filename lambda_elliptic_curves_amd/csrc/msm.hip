@@ -345,7 +345,8 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
 constexpr uint32_t SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 
 __device__ __forceinline__ uint32_t scan_len(const uint32_t *in, uint32_t k, int mode) { return mode ? (in[k + 1] - in[k]) : in[k]; }
-__device__ __forceinline__ uint32_t scan_val(uint32_t len, uint32_t chunk) { return chunk ? (len + chunk - 1) / chunk : len; }   // chunk 0 = mode 0
+// chunk 0 = mode 0.  In chunk mode an empty segment still gets one (empty) piece, so that every key owns an output slot
+__device__ __forceinline__ uint32_t scan_val(uint32_t len, uint32_t chunk) { return chunk ? max(1u, (len + chunk - 1) / chunk) : len; }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_partial_kernel(const uint32_t *in, uint32_t K, int mode, uint32_t *bsum,
                                                                       uint32_t *bmax) {
@@ -435,6 +436,103 @@ __global__ __launch_bounds__(SCAN_BLOCK) void msm_scan_final_kernel(const uint32
         if (k < K) out[k] = run;
         run += v[i];
     }
+}
+
+// ---- piece order: the accumulate work-items sorted by their number of additions --------------------------------
+// A wave runs as long as its longest piece.  Bucket lengths of uniform scalars are Poisson (mean 16 at 2^20 points with
+// c = 16: the longest of 64 neighbours is ~25), so work-items are handed their pieces in descending order of length: a
+// counting sort of the piece ids by length (<= ORDER_BINS - 1) — every wave then holds pieces of one length.
+//   out_off == nullptr: piece t is the key t, length seg_off[t+1] - seg_off[t]
+//   else:               key k owns the pieces out_off[k] .. out_off[k+1]-1 (at least one), equal shares of its segment
+// pass 0 counts the lengths, pass 1 (same walk) scatters: perm_t[rank] = piece id, perm_key[rank] = its key.
+constexpr uint32_t ORDER_BINS = 130;    // lengths 0 .. 128 (MSM_CH <= 128) + slack
+constexpr uint32_t ORDER_PER = 8;       // consecutive pieces per work-item
+__device__ __forceinline__ uint32_t order_first_key(const uint32_t *out_off, uint32_t K, uint32_t t) {
+    uint32_t lo = 0, hi = K;   // largest key with out_off[key] <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (out_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+template <bool SCATTER>
+__global__ __launch_bounds__(SORT_THREADS) void msm_piece_order_kernel(const uint32_t *seg_off, const uint32_t *out_off, uint32_t K,
+                                                                      uint32_t P, uint32_t *bin_cnt, uint32_t *bin_cursor,
+                                                                      uint32_t *perm_t, uint32_t *perm_key) {
+    __shared__ uint32_t h[ORDER_BINS], base[ORDER_BINS];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t b = tid; b < ORDER_BINS; b += SORT_THREADS) h[b] = 0;
+    __syncthreads();
+    const uint32_t t0 = (blockIdx.x * SORT_THREADS + tid) * ORDER_PER;
+    uint32_t key = 0, o0 = 0, o1 = 0, s0 = 0, len = 0;
+    uint32_t bin[ORDER_PER], rk[ORDER_PER], kk[ORDER_PER];
+    if (t0 < P && out_off) {
+        key = order_first_key(out_off, K, t0);
+        o0 = out_off[key]; o1 = out_off[key + 1]; s0 = seg_off[key]; len = seg_off[key + 1] - s0;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < ORDER_PER; q++) {
+        const uint32_t t = t0 + q;
+        bin[q] = ORDER_BINS;
+        if (t >= P) continue;
+        uint32_t L;
+        if (out_off) {
+            while (t >= o1) {   // every key owns at least one piece: at most one step per piece
+                key++;
+                o0 = o1; o1 = out_off[key + 1]; s0 = seg_off[key]; len = seg_off[key + 1] - s0;
+            }
+            const uint32_t np = o1 - o0, j = t - o0;
+            L = (uint32_t)(((uint64_t)len * (j + 1)) / np) - (uint32_t)(((uint64_t)len * j) / np);
+            kk[q] = key;
+        } else {
+            L = seg_off[t + 1] - seg_off[t];
+            kk[q] = t;
+        }
+        bin[q] = ORDER_BINS - 1 - min(L, ORDER_BINS - 1);   // long pieces first
+        rk[q] = atomicAdd(&h[bin[q]], 1u);
+    }
+    __syncthreads();
+    if constexpr (!SCATTER) {
+        for (uint32_t b = tid; b < ORDER_BINS; b += SORT_THREADS)
+            if (h[b]) atomicAdd(&bin_cnt[b], h[b]);
+    } else {
+        if (tid == 0) {   // exclusive scan of the global bin counts (130 values)
+            uint32_t run = 0;
+            for (uint32_t b = 0; b < ORDER_BINS; b++) { base[b] = run; run += bin_cnt[b]; }
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < ORDER_BINS; b += SORT_THREADS)
+            base[b] += h[b] ? atomicAdd(&bin_cursor[b], h[b]) : 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < ORDER_PER; q++)
+            if (bin[q] < ORDER_BINS) {
+                const uint32_t r = base[bin[q]] + rk[q];
+                perm_t[r] = t0 + q;
+                if (perm_key) perm_key[r] = kk[q];
+            }
+    }
+}
+// order_tmp: 2 * ORDER_BINS u32
+void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t *out_off, uint32_t K, uint32_t P, uint32_t *order_tmp,
+                            uint32_t *perm_t, uint32_t *perm_key, hipStream_t s) {
+    hipMemsetAsync(order_tmp, 0, 8 * ORDER_BINS, s);
+    const uint32_t blocks = (P + SORT_THREADS * ORDER_PER - 1) / (SORT_THREADS * ORDER_PER);
+    hipEvent_t pe = c.prof_begin(s);
+    hipLaunchKernelGGL((msm_piece_order_kernel<false>), dim3(blocks), dim3(SORT_THREADS), 0, s, seg_off, out_off, K, P, order_tmp,
+                       order_tmp + ORDER_BINS, perm_t, perm_key);
+    hipLaunchKernelGGL((msm_piece_order_kernel<true>), dim3(blocks), dim3(SORT_THREADS), 0, s, seg_off, out_off, K, P, order_tmp,
+                       order_tmp + ORDER_BINS, perm_t, perm_key);
+    c.prof_end("msm_piece_order_kernel", pe, s);
+}
+size_t msm_order_tmp_bytes() { return 8 * ORDER_BINS; }
+uint32_t msm_ch() {   // max points per accumulate work-item (LW_HIP_MSM_CH: tuning only)
+    static uint32_t v = [] { const char *e = getenv("LW_HIP_MSM_CH"); int x = e ? atoi(e) : 32; return (uint32_t)(x < 4 ? 4 : (x > 128 ? 128 : x)); }();
+    return v;
+}
+int msm_piece_order_enabled() {
+    static int v = [] { const char *e = getenv("LW_HIP_MSM_ORDER"); return e ? atoi(e) : 1; }();
+    return v;
 }
 
 uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W) {

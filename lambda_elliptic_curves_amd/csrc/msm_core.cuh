@@ -9,7 +9,8 @@
 
 namespace lw {
 
-constexpr uint32_t MSM_CH = 32;        // max points per accumulate work-item (a bucket is cut into equal pieces <= CH; 64 measured 1 ms slower at 2^24)
+uint32_t msm_ch();                     // max points per accumulate work-item (a bucket is cut into equal pieces <= CH = 32; 64 measured 1 ms slower at 2^24)
+int msm_piece_order_enabled();         // LW_HIP_MSM_ORDER=0: work-items take their pieces in key order (A/B)
 uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
@@ -21,6 +22,9 @@ void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t c
                      uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
 size_t msm_scan_scratch_bytes(uint32_t K);
+void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t *out_off, uint32_t K, uint32_t P, uint32_t *order_tmp,
+                            uint32_t *perm_t, uint32_t *perm_key, hipStream_t s);
+size_t msm_order_tmp_bytes();
 int msm_waves_per_simd();   // LW_HIP_MSM_WAVES (2 or 3): register budget of the accumulate kernel
 
 // ---------------------------------------------------------------- accumulate
@@ -42,15 +46,22 @@ __device__ __forceinline__ void pt_st(void *base, size_t i, const Point<C> &p) {
 template <class C, int WAVES, bool AFFINE>
 __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *pts, const uint32_t *index,
                                                                              const uint32_t *seg_off, const uint32_t *out_off,
+                                                                             const uint32_t *perm_t, const uint32_t *perm_key,
                                                                              uint32_t K, uint32_t total_items, void *pout) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_items) return;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_items) return;
+    // perm_t: pieces in descending order of length (msm_piece_order_kernel), so the lanes of a wave run equally long
+    const uint32_t t = perm_t ? perm_t[r] : r;
     uint32_t b, e;
     if (out_off) {
         uint32_t lo = 0, hi = K;   // largest key with out_off[key] <= t
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (out_off[mid] <= t) lo = mid; else hi = mid;
+        if (perm_key) {
+            lo = perm_key[r];
+        } else {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (out_off[mid] <= t) lo = mid; else hi = mid;
+            }
         }
         // the key's items are cut into np = ceil(len / CH) pieces of equal length (+-1), so the lanes of a wave run
         // the same number of additions instead of full pieces next to a short remainder
@@ -336,17 +347,39 @@ struct MsmRunner {
             if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
         }
         // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
+        const uint32_t CH = msm_ch();
+        const bool ordered = msm_piece_order_enabled() != 0;   // first round only: later rounds sum equal numbers of partials
+        uint32_t *order_tmp = (uint32_t *)cv.take(msm_order_tmp_bytes());
         const uint32_t *seg = off;
         const void *pts = d_points;         // first round: the caller's points through the sorted index list
         const uint32_t *index = sorted;
         uint64_t len = maxlen;             // longest segment
         uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
-        while (len > MSM_CH) {
+        bool first = true;                 // (the dry run has no pointers to tell the rounds apart)
+        auto launch = [&](const uint32_t *out_off, const uint32_t *perm_t, const uint32_t *perm_key, uint32_t total, void *pout,
+                          const char *name) {
+            const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
+            hipEvent_t pe = c.prof_begin(stream);
+            if (index && affine)
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                   out_off, perm_t, perm_key, K, total, pout);
+            else if (out_off && C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::ACC_WAVES == 2 ? 3 : C::ACC_WAVES), false>), dim3(blocks), dim3(MSM_THREADS), 0,
+                                   stream, pts, index, seg, out_off, perm_t, perm_key, K, total, pout);
+            else
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                                   out_off, perm_t, perm_key, K, total, pout);
+            c.prof_end(name, pe, stream);
+        };
+        while (len > CH) {
             uint32_t *out_off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
-            uint64_t out_bound = items_bound / MSM_CH + K;
+            uint64_t out_bound = items_bound / CH + K;
             char *pout = (char *)cv.take(PB * out_bound);
+            const bool ord = ordered && first;
+            uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * out_bound) : nullptr;
+            uint32_t *perm_key = ord ? (uint32_t *)cv.take(4 * out_bound) : nullptr;
             if (!dry) {
-                msm_launch_scan(seg, out_off, K, (int)MSM_CH, maxlen_d, scan_tmp, stream);
+                msm_launch_scan(seg, out_off, K, (int)CH, maxlen_d, scan_tmp, stream);
                 uint32_t total = 0;
                 LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
                 LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
@@ -354,38 +387,24 @@ struct MsmRunner {
                     set_error("internal: MSM partial count %u exceeds bound %llu", total, (unsigned long long)out_bound);
                     return LW_ERR_LAUNCH;
                 }
-                if (total) {
-                    const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
-                    hipEvent_t pe = c.prof_begin(stream);
-                    if (index && affine)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
-                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
-                    else if (C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::ACC_WAVES == 2 ? 3 : C::ACC_WAVES), false>), dim3(blocks),
-                                           dim3(MSM_THREADS), 0, stream, pts, index, seg, (const uint32_t *)out_off, K, total, (void *)pout);
-                    else
-                        hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index,
-                                           seg, (const uint32_t *)out_off, K, total, (void *)pout);
-                    c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>", pe, stream);
-                }
+                if (ord) msm_launch_piece_order(c, seg, out_off, K, total, order_tmp, perm_t, perm_key, stream);
+                if (total) launch(out_off, perm_t, perm_key, total, (void *)pout, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>");
             }
             seg = out_off;
             pts = pout;
             index = nullptr;
-            len = (len + MSM_CH - 1) / MSM_CH;
+            first = false;
+            len = (len + CH - 1) / CH;
             items_bound = out_bound;
         }
         char *buckets = (char *)cv.take(PB * (size_t)K);
-        if (!dry) {
-            const uint32_t blocks = (K + MSM_THREADS - 1) / MSM_THREADS;
-            hipEvent_t pe = c.prof_begin(stream);
-            if (index && affine)
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                   (const uint32_t *)nullptr, K, K, (void *)buckets);
-            else
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                   (const uint32_t *)nullptr, K, K, (void *)buckets);
-            c.prof_end(index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>", pe, stream);
+        {
+            const bool ord = ordered && first;
+            uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * (size_t)K) : nullptr;
+            if (!dry) {
+                if (ord) msm_launch_piece_order(c, seg, nullptr, K, K, order_tmp, perm_t, nullptr, stream);
+                launch(nullptr, perm_t, nullptr, K, (void *)buckets, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
+            }
         }
         char *A_unused;
         return reduce(buckets, 1u << cbits, W, cv, S_out, &A_unused);
