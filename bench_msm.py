@@ -235,9 +235,11 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, 
     from bench import traffic_entry, pmc_counter
     traffic, traffic_src = traffic_entry("msm", L)
     # additions the device's accumulation performs: one per (point, window) item minus one per non-empty bucket
-    dev_c = 8 if L < 17 else 16            # csrc/msm_core.cuh pick_window
-    dev_w = (256 + dev_c - 1) // dev_c
-    dev_adds = max(n * dev_w - dev_w * ((1 << dev_c) - 1), 0)
+    # (signed digits, csrc/msm.hip: W = ceil(257/c) windows of 2^(c-1) buckets; csrc/msm_core.cuh pick_window)
+    dev_c = int(os.environ.get("LW_HIP_MSM_C", 0)) or (8 if L < 15 else 16 if L < 23 else 20)
+    dev_w = (256 + dev_c) // dev_c
+    dev_items = n * (dev_w - 1) if 256 % dev_c == 0 else n * dev_w      # the window at bit 256 is empty for scalars below 2^255
+    dev_adds = max(dev_items - dev_w * (1 << (dev_c - 1)), 0)
     return {
         "metric": "MSM G1 point-adds/sec (BLS12-381, 2^%d distinct points, reference add count adds_ref(N))" % L,
         "value": world * adds_ref(n) * steps / dt, "unit": "point-adds/s",

@@ -47,20 +47,41 @@ void msm_launch_scalar_prep(int bn254, const void *in, void *out, uint64_t n, hi
     else hipLaunchKernelGGL((msm_scalars_from_mont_kernel<Fr381>), grid, dim3(256), 0, s, in, out, n);
 }
 
-// ---- bucket scatter: two-level counting sort of (point index) by key = (window, digit) ----------------------
-// Level 0 cuts every scalar into its W digits once (msm_digits_kernel: 32 B read, W x 2 B written per point), so the
-// per-window passes below read 2 bytes per point instead of the whole scalar.
-// Level A partitions the N items of ONE window (grid.y = window) into coarse bins (high digit bits): a workgroup takes
+// ---- bucket scatter: two-level counting sort of (point index, sign) by key = (window, |digit| - 1) -------------
+// Digits are SIGNED: with u = (c raw bits) + carry, u > 2^(c-1) becomes the digit u - 2^c and carries one into the next
+// window, so |digit| <= 2^(c-1) and a window has 2^(c-1) buckets — half the running-sum work of the reference's unsigned
+// digits (pippenger.rs:76-81) for the same c, which is what makes c = 20 affordable at 2^24 points (13 windows instead
+// of 16: 19 % fewer bucket additions).  A negative digit adds -P (one field negation of y in the accumulate kernel).
+// W = ceil(257 / c) windows, so the top window never carries out (scalars are below 2^256).  Same group element as the
+// reference's sum; bucket j of a window stands for the multiplier j + 1.
+// Level 0 cuts every scalar into its W digits once (msm_digits_kernel: 32 B read, W x 4 B written per point), so the
+// per-window passes below read 4 bytes per point instead of the whole scalar.
+// Level A partitions the N items of ONE window (grid.y = window) into coarse bins (high key bits): a workgroup takes
 // 16384 points, histograms them in LDS, reserves one contiguous run per bin with a single global atomic and writes its
-// items of that bin into the run (ranks from LDS atomics) — runs average 64 items (256 B).  The first version of this
-// level did all W windows in one workgroup of 1024 points: 4096 bins per workgroup, 4-item runs and 67 M contended
-// global atomics (16384 workgroups x 4096 counters); that was 6.8 of the sort's 9.5 ms at 2^24.
-// Level B gives every coarse bin to one workgroup, which counting-sorts it by the low 8 digit bits through LDS and emits
-// the per-key offsets the accumulation needs.
-constexpr uint32_t SORT_FINE_BITS = 8;
+// items of that bin into the run (ranks from LDS atomics).  The first version of this level did all W windows in one
+// workgroup of 1024 points: 4096 bins per workgroup, 4-item runs and 67 M contended global atomics (16384 workgroups x
+// 4096 counters); that was 6.8 of the sort's 9.5 ms at 2^24.
+// Level B gives every coarse bin to one or more workgroups, which counting-sort it by the low key bits through LDS and
+// emit the per-key offsets the accumulation needs.
 constexpr uint32_t SORT_PPB = 16384;            // points per level-A workgroup (one window)
 constexpr uint32_t SORT_THREADS = 256;
-constexpr uint32_t SORT_MAX_COARSE = 256;       // coarse bins per window: 2^(c - 8) <= 2^8 (c <= 16)
+constexpr uint32_t SORT_MAX_COARSE = 512;       // coarse bins per window
+constexpr uint32_t SORT_MAX_FINE = 1024;        // keys per coarse bin
+constexpr uint32_t MSM_MAX_C = 20;              // key bits c - 1 <= 9 + 10
+
+// split of the c - 1 key bits of a window into (coarse, fine) and the item width.  Narrow items (32 bits: fine digit << 25
+// | sign << 24 | index) halve the traffic of the intermediate list; they fit up to 2^24 points and 7 fine bits.
+struct SortSplit { uint32_t kb, fine, hb; bool wide; };
+static SortSplit sort_split(uint32_t c, uint64_t n) {
+    SortSplit sp;
+    sp.kb = c - 1;
+    sp.wide = n > (1ull << 24) || sp.kb > 15;
+    const uint32_t fmax = sp.wide ? 10u : 7u;
+    sp.fine = sp.kb < fmax ? sp.kb : fmax;
+    sp.hb = sp.kb - sp.fine;
+    if (sp.hb > 9) { sp.hb = 9; sp.fine = sp.kb - 9; }   // wide only: kb <= 19 keeps fine <= 10
+    return sp;
+}
 
 __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint64_t i, uint32_t *s) {
     const uint4 *q = reinterpret_cast<const uint4 *>(scalars + i * 8);
@@ -68,13 +89,13 @@ __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint6
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
 }
 
-// dig[w * n_pad + i] = digit w of scalar i (unsigned c-bit digits, pippenger.rs:76-77); rows padded with zeros to n_pad.
-// The scalar's words are walked with compile-time register indices (a runtime word index would send the eight words
-// through scratch memory: 3.2 ms instead of 0.4 at 2^24).
+// dig[w * n_pad + i] = (|d| << 1) | (d < 0) for the signed digit d of window w of scalar i; 0 when d = 0; rows padded with
+// zeros to n_pad.  The scalar's words are walked with compile-time register indices (a runtime word index would send the
+// eight words through scratch memory: 3.2 ms instead of 0.4 at 2^24).
 constexpr uint32_t DIGITS_PER_THREAD = 8;   // points per work-item: 8192 workgroups at 2^24 instead of 65536 tiny ones
 __global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars, uint64_t n, uint64_t n_pad, uint32_t c, uint32_t W,
-                                                         uint16_t *dig) {
-    const uint32_t mask = (1u << c) - 1;
+                                                         uint32_t *dig) {
+    const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
     const uint64_t i0 = (uint64_t)blockIdx.x * (256 * DIGITS_PER_THREAD) + threadIdx.x;
 #pragma nounroll
     for (uint32_t q = 0; q < DIGITS_PER_THREAD; q++) {
@@ -83,101 +104,135 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars
         uint32_t s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (i < n) load_scalar_words(scalars, i, s);
         const uint32_t t[9] = {s[6], s[7], s[4], s[5], s[2], s[3], s[0], s[1], 0u};   // 32-bit words, least significant first
-        uint32_t o = 0, w = 0;
-        uint16_t *out = dig + i;
+        uint32_t o = 0, w = 0, carry = 0;
+        uint32_t *out = dig + i;
+        auto emit = [&](uint32_t raw) {
+            const uint32_t u = raw + carry;                 // 0 .. 2^c
+            const uint32_t neg = u > half;
+            const uint32_t m = neg ? (mask + 1 - u) : u;    // |digit| <= 2^(c-1)
+            carry = neg;
+            out[(uint64_t)w * n_pad] = m ? ((m << 1) | neg) : 0u;
+            w++;
+        };
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
             const uint64_t v = (uint64_t)t[j] | ((uint64_t)t[j + 1] << 32);
             while (w < W && o < 32u * (j + 1)) {
-                out[(uint64_t)w * n_pad] = (uint16_t)((uint32_t)(v >> (o - 32u * j)) & mask);
+                emit((uint32_t)(v >> (o - 32u * j)) & mask);
                 o += c;
-                w++;
             }
         }
+        while (w < W) emit(0u);   // a window that starts at bit 256 (c divides 256) holds only the carry
     }
 }
 
-// An item is (fine digit, point index): 32 bits (digit << 24 | index) when the index fits 24 bits, which halves the
-// traffic of the intermediate list at the sizes that matter most (N <= 2^24), else 64 bits (digit << 32 | index).
+// An item is (fine key bits, sign, point index).
 template <class ITEM> struct ItemPack;
 template <> struct ItemPack<uint32_t> {
-    static __device__ __forceinline__ uint32_t make(uint32_t fine, uint64_t idx) { return (fine << 24) | (uint32_t)idx; }
-    static __device__ __forceinline__ uint32_t fine(uint32_t it) { return it >> 24; }
-    static __device__ __forceinline__ uint32_t index(uint32_t it) { return it & 0xffffffu; }
+    static __device__ __forceinline__ uint32_t make(uint32_t fine, uint32_t neg, uint64_t idx) { return (fine << 25) | (neg << 24) | (uint32_t)idx; }
+    static __device__ __forceinline__ uint32_t fine(uint32_t it) { return it >> 25; }
+    static __device__ __forceinline__ uint32_t entry(uint32_t it) { return (it & 0xffffffu) | ((it << 7) & 0x80000000u); }
 };
 template <> struct ItemPack<uint64_t> {
-    static __device__ __forceinline__ uint64_t make(uint32_t fine, uint64_t idx) { return ((uint64_t)fine << 32) | (uint32_t)idx; }
+    static __device__ __forceinline__ uint64_t make(uint32_t fine, uint32_t neg, uint64_t idx) { return ((uint64_t)fine << 32) | (neg << 31) | (uint32_t)idx; }
     static __device__ __forceinline__ uint32_t fine(uint64_t it) { return (uint32_t)(it >> 32); }
-    static __device__ __forceinline__ uint32_t index(uint64_t it) { return (uint32_t)it; }
+    static __device__ __forceinline__ uint32_t entry(uint64_t it) { return (uint32_t)it; }
 };
+// entry of the sorted list handed to the accumulate kernel: sign << 31 | point index
+
+// exclusive scan of a[0 .. NMAX) in LDS by the whole workgroup (tmp: SORT_THREADS words); returns the total
+template <uint32_t NMAX>
+__device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t *a, uint32_t *tmp) {
+    constexpr uint32_t PER = NMAX / SORT_THREADS;
+    static_assert(PER * SORT_THREADS == NMAX, "scan size");
+    const uint32_t tid = threadIdx.x;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+        v[i] = a[tid * PER + i];
+        sum += v[i];
+    }
+    tmp[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
+        const uint32_t x = tid >= d ? tmp[tid - d] : 0;
+        __syncthreads();
+        tmp[tid] += x;
+        __syncthreads();
+    }
+    const uint32_t total = tmp[SORT_THREADS - 1];
+    uint32_t run = tmp[tid] - sum;
+#pragma unroll
+    for (uint32_t i = 0; i < PER; i++) {
+        a[tid * PER + i] = run;
+        run += v[i];
+    }
+    __syncthreads();
+    return total;
+}
 
 // pass A0 (msm_coarse_count_kernel): coarse histogram.  pass A1 (msm_coarse_kernel): scatter packed items into the runs reserved per coarse bin.
-// grid = (ceil(n_pad / SORT_PPB), W); eight digits (one uint4) per load.  The scatter stages every COARSE_CHUNK points in
-// LDS in bin order and writes them out linearly, so a bin's share of the chunk (32 items on average) leaves as one
-// contiguous run; storing each item straight from its lane (4-byte stores into up to 64 runs per instruction) took 2.3 ms.
+// grid = (ceil(n_pad / SORT_PPB), W); four digits (one uint4) per load.  The scatter stages every COARSE_CHUNK points in
+// LDS in bin order and writes them out linearly, so a bin's share of the chunk leaves as one contiguous run; storing each
+// item straight from its lane (4-byte stores into up to 64 runs per instruction) took 2.3 ms.  A staged item is 32 bits
+// whatever the item width: position in the chunk (13 bits) | sign << 13 | fine key bits << 14.
 constexpr uint32_t COARSE_CHUNK = 8192;
-constexpr int COARSE_LOADS = COARSE_CHUNK / 8 / SORT_THREADS;   // uint4 loads per work-item and chunk
-__device__ __forceinline__ uint32_t digit_of(const uint4 &v, int e) {
-    const uint32_t word = e < 2 ? v.x : e < 4 ? v.y : e < 6 ? v.z : v.w;
-    return (e & 1) ? (word >> 16) : (word & 0xffffu);
-}
-__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const uint16_t *dig, uint64_t n_pad, uint32_t c, uint32_t fine_bits,
+constexpr int COARSE_LOADS = COARSE_CHUNK / 4 / SORT_THREADS;   // uint4 loads per work-item and chunk
+__device__ __forceinline__ uint32_t digit_of(const uint4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+// coarse bin of an encoded digit (SORT_MAX_COARSE = the dummy slot of zero digits, which contribute nothing, pippenger.rs:78)
+__device__ __forceinline__ uint32_t coarse_bin(uint32_t enc, uint32_t fine_bits) { return enc ? (((enc >> 1) - 1) >> fine_bits) : SORT_MAX_COARSE; }
+
+__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
                                                                        uint32_t *coarse_cnt) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];
-    const uint32_t hb = c - fine_bits, NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
     for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
-    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 8);
-    const uint64_t q1 = min(n_pad / 8, q0 + SORT_PPB / 8);
+    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
+    const uint64_t q1 = min(n_pad / 4, q0 + SORT_PPB / 4);
     const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
     for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
         const uint4 v = d4[q];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t d = digit_of(v, e);
-            atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
-        }
+        for (int e = 0; e < 4; e++) atomicAdd(&h[coarse_bin(digit_of(v, e), fine_bits)], 1u);
     }
     __syncthreads();
     for (uint32_t b = tid; b < NB; b += SORT_THREADS)
         if (h[b]) atomicAdd(&coarse_cnt[(w << hb) + b], h[b]);
 }
 template <class ITEM>
-__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint16_t *dig, uint64_t n_pad, uint32_t c, uint32_t fine_bits,
+__global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
                                                                  const uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items) {
-    __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits (digit 0 contributes nothing, pippenger.rs:78)
+    __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
     __shared__ uint32_t base[SORT_MAX_COARSE];    // next free slot of this workgroup's run per bin
-    __shared__ uint32_t pre[SORT_MAX_COARSE];     // scan workspace / chunk-local exclusive offsets
-    __shared__ ITEM buf[COARSE_CHUNK];
-    __shared__ uint8_t bbin[COARSE_CHUNK];        // bin of every staged item (the packed item keeps only the fine digit)
-    const uint32_t hb = c - fine_bits, NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
+    __shared__ uint32_t pre[SORT_MAX_COARSE];     // chunk-local exclusive offsets
+    __shared__ uint32_t tmp[SORT_THREADS];
+    __shared__ uint32_t buf[COARSE_CHUNK];
+    __shared__ uint16_t bbin[COARSE_CHUNK];       // bin of every staged item
+    const uint32_t NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t bin0 = w << hb;
     for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
-    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 8);
-    const uint64_t q1 = min(n_pad / 8, q0 + SORT_PPB / 8);
+    const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
+    const uint64_t q1 = min(n_pad / 4, q0 + SORT_PPB / 4);
     const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
     for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
         const uint4 v = d4[q];
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t d = digit_of(v, e);
-            atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
-        }
+        for (int e = 0; e < 4; e++) atomicAdd(&h[coarse_bin(digit_of(v, e), fine_bits)], 1u);
     }
     __syncthreads();
-    {   // one global atomic per bin reserves this workgroup's run
-        const uint32_t cnt = tid < NB ? h[tid] : 0;
-        base[tid] = cnt ? coarse_off[bin0 + tid] + atomicAdd(&coarse_cursor[bin0 + tid], cnt) : 0;
+    for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) {   // one global atomic per bin reserves this workgroup's run
+        const uint32_t cnt = b < NB ? h[b] : 0;
+        base[b] = cnt ? coarse_off[bin0 + b] + atomicAdd(&coarse_cursor[bin0 + b], cnt) : 0;
     }
     __syncthreads();
     const uint32_t fmask = (1u << fine_bits) - 1;
-    for (uint64_t qc = q0; qc < q1; qc += COARSE_CHUNK / 8) {
-        h[tid] = 0;
-        if (tid == 0) h[SORT_MAX_COARSE] = 0;
+    for (uint64_t qc = q0; qc < q1; qc += COARSE_CHUNK / 4) {
+        for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
         __syncthreads();
         uint4 v[COARSE_LOADS];
-        uint32_t rk[COARSE_LOADS][8];
+        uint32_t rk[COARSE_LOADS][4];
 #pragma unroll
         for (int l = 0; l < COARSE_LOADS; l++) {
             const uint64_t q = qc + l * SORT_THREADS + tid;
@@ -186,56 +241,43 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint16_t
 #pragma unroll
         for (int l = 0; l < COARSE_LOADS; l++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint32_t d = digit_of(v[l], e);
-                rk[l][e] = atomicAdd(&h[d ? (d >> fine_bits) : SORT_MAX_COARSE], 1u);
-            }
+            for (int e = 0; e < 4; e++) rk[l][e] = atomicAdd(&h[coarse_bin(digit_of(v[l], e), fine_bits)], 1u);
         __syncthreads();
-        const uint32_t lcnt = h[tid];             // items of bin `tid` in this chunk (zero digits are in the dummy slot)
-        pre[tid] = lcnt;
+        for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) pre[b] = h[b];   // zero digits stay in the dummy slot
         __syncthreads();
-        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-            const uint32_t x = tid >= d ? pre[tid - d] : 0;
-            __syncthreads();
-            pre[tid] += x;
-            __syncthreads();
-        }
-        const uint32_t total = pre[SORT_THREADS - 1];
-        const uint32_t lex = pre[tid] - lcnt;
-        __syncthreads();
-        pre[tid] = lex;
-        __syncthreads();
+        const uint32_t total = block_scan_exclusive<SORT_MAX_COARSE>(pre, tmp);
 #pragma unroll
         for (int l = 0; l < COARSE_LOADS; l++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint32_t d = digit_of(v[l], e);
-                if (d) {
-                    const uint32_t pos = pre[d >> fine_bits] + rk[l][e];
-                    buf[pos] = ItemPack<ITEM>::make(d & fmask, (qc + l * SORT_THREADS + tid) * 8 + e);
-                    bbin[pos] = (uint8_t)(d >> fine_bits);
+            for (int e = 0; e < 4; e++) {
+                const uint32_t enc = digit_of(v[l], e);
+                if (enc) {
+                    const uint32_t key = (enc >> 1) - 1, bin = key >> fine_bits;
+                    const uint32_t pos = pre[bin] + rk[l][e];
+                    buf[pos] = ((uint32_t)(l * SORT_THREADS + tid) * 4 + e) | ((enc & 1) << 13) | ((key & fmask) << 14);
+                    bbin[pos] = (uint16_t)bin;
                 }
             }
         __syncthreads();
         for (uint32_t e = tid; e < total; e += SORT_THREADS) {
-            const uint32_t bin = bbin[e];
-            items[base[bin] + (e - pre[bin])] = buf[e];
+            const uint32_t bin = bbin[e], st = buf[e];
+            items[base[bin] + (e - pre[bin])] = ItemPack<ITEM>::make(st >> 14, (st >> 13) & 1, qc * 4 + (st & 0x1fffu));
         }
         __syncthreads();
-        base[tid] += lcnt;
+        for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) base[b] += h[b];
         __syncthreads();
     }
 }
 
-// pass B: counting sort of every coarse bin by the fine digit; writes the sorted indices; the per-key offsets come from
-// a scan of the key counts.  A coarse bin is cut into sub-blocks of FINE_SUB items, one workgroup each, so a skewed
-// scalar distribution (a prover's witness is mostly 0 / 1 / small values: one key of window 0 then holds a large share of
-// all items, and every short top window puts all its items into a handful of keys) costs more workgroups, not one
-// serial workgroup walking millions of items — the round-1 kernel (one workgroup per coarse bin) took 8 ms for a 4 M-item
-// bin.  B0 counts the keys (LDS histogram per sub-block, one global atomic per non-empty key); B1 takes its sub-block in
-// chunks of FINE_CHUNK items, counting-sorts a chunk inside LDS, reserves a run per key with one global atomic and writes
-// the chunk out linearly, so every key receives its share of the chunk as one contiguous run (32 items = 128 B on
-// average for uniform scalars) instead of single 4-byte stores scattered over 256 cursors.
+// pass B: counting sort of every coarse bin by the fine key bits; writes the sorted (sign, index) entries; the per-key
+// offsets come from a scan of the key counts.  A coarse bin is cut into sub-blocks of FINE_SUB items, one workgroup each,
+// so a skewed scalar distribution (a prover's witness is mostly 0 / 1 / small values: one key of window 0 then holds a
+// large share of all items, and a short top window puts all its items into a fraction of the keys) costs more
+// workgroups, not one serial workgroup walking millions of items — the round-1 kernel (one workgroup per coarse bin) took
+// 8 ms for a 4 M-item bin.  B0 counts the keys (LDS histogram per sub-block, one global atomic per non-empty key); B1
+// takes its sub-block in chunks of FINE_CHUNK items, counting-sorts a chunk inside LDS, reserves a run per key with one
+// global atomic and writes the chunk out linearly, so every key receives its share of the chunk as one contiguous run
+// instead of single 4-byte stores scattered over the cursors.
 constexpr uint32_t FINE_SUB = 131072;
 constexpr uint32_t FINE_CHUNK = 8192;
 constexpr int FINE_PER = FINE_CHUNK / SORT_THREADS;
@@ -244,7 +286,7 @@ constexpr int FINE_PER = FINE_CHUNK / SORT_THREADS;
 __device__ __forceinline__ bool fine_locate(const uint32_t *coarse_off, const uint32_t *sub_off, uint32_t CB, uint32_t blk,
                                             uint32_t &bin, uint32_t &i0, uint32_t &i1) {
     if (blk >= sub_off[CB]) return false;
-    uint32_t lo = 0, hi = CB;   // largest bin with sub_off[bin] <= blk (that bin is non-empty: sub_off[bin + 1] > blk)
+    uint32_t lo = 0, hi = CB;   // largest bin with sub_off[bin] <= blk (sub-blocks are counted with at least one per bin)
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (sub_off[mid] <= blk) lo = mid; else hi = mid;
@@ -259,11 +301,11 @@ __device__ __forceinline__ bool fine_locate(const uint32_t *coarse_off, const ui
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
                                                                      uint32_t CB, uint32_t fine_bits, uint32_t *key_cnt) {
-    __shared__ uint32_t h[1 << SORT_FINE_BITS];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t h[SORT_MAX_FINE];
+    const uint32_t tid = threadIdx.x, NF = 1u << fine_bits;
     uint32_t bin, i0, i1;
     if (!fine_locate(coarse_off, sub_off, CB, blockIdx.x, bin, i0, i1)) return;
-    h[tid] = 0;
+    for (uint32_t k = tid; k < NF; k += SORT_THREADS) h[k] = 0;
     __syncthreads();
     for (uint32_t i = i0 + tid; i < i1; i += 8 * SORT_THREADS) {
         ITEM it[8];
@@ -277,24 +319,26 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM
             if (i + j * SORT_THREADS < i1) atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
     }
     __syncthreads();
-    if (tid < (1u << fine_bits) && h[tid]) atomicAdd(&key_cnt[(bin << fine_bits) | tid], h[tid]);
+    for (uint32_t k = tid; k < NF; k += SORT_THREADS)
+        if (h[k]) atomicAdd(&key_cnt[(bin << fine_bits) | k], h[k]);
 }
 
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
                                                                uint32_t CB, uint32_t fine_bits, const uint32_t *off, uint32_t *key_cursor,
                                                                uint32_t *sorted) {
-    __shared__ uint32_t h[1 << SORT_FINE_BITS];     // chunk-local counts
-    __shared__ uint32_t pre[1 << SORT_FINE_BITS];   // scan workspace, then chunk-local exclusive offsets
-    __shared__ uint32_t run[1 << SORT_FINE_BITS];   // start of this chunk's run in `sorted`, per fine digit
+    __shared__ uint32_t h[SORT_MAX_FINE];     // chunk-local counts
+    __shared__ uint32_t pre[SORT_MAX_FINE];   // chunk-local exclusive offsets
+    __shared__ uint32_t run[SORT_MAX_FINE];   // start of this chunk's run in `sorted`, per fine key
+    __shared__ uint32_t tmp[SORT_THREADS];
     __shared__ ITEM buf[FINE_CHUNK];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, NF = 1u << fine_bits;
     uint32_t bin, i0, i1;
     if (!fine_locate(coarse_off, sub_off, CB, blockIdx.x, bin, i0, i1)) return;
     const uint32_t key0 = bin << fine_bits;
     for (uint32_t c0 = i0; c0 < i1; c0 += FINE_CHUNK) {
         const uint32_t cn = min(FINE_CHUNK, i1 - c0);
-        h[tid] = 0;
+        for (uint32_t k = tid; k < SORT_MAX_FINE; k += SORT_THREADS) h[k] = 0;
         __syncthreads();
         ITEM it[FINE_PER];
         uint32_t rk[FINE_PER];
@@ -307,20 +351,13 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
         for (int j = 0; j < FINE_PER; j++)
             if (j * SORT_THREADS + tid < cn) rk[j] = atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
         __syncthreads();
-        const uint32_t lcnt = h[tid];
-        run[tid] = lcnt ? off[key0 + tid] + atomicAdd(&key_cursor[key0 + tid], lcnt) : 0;   // lcnt > 0 only below 2^fine_bits
-        pre[tid] = lcnt;
-        __syncthreads();
-        for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-            const uint32_t x = tid >= d ? pre[tid - d] : 0;
-            __syncthreads();
-            pre[tid] += x;
-            __syncthreads();
+        for (uint32_t k = tid; k < SORT_MAX_FINE; k += SORT_THREADS) {
+            const uint32_t lcnt = h[k];   // > 0 only below NF
+            run[k] = lcnt ? off[key0 + k] + atomicAdd(&key_cursor[key0 + k], lcnt) : 0;
+            pre[k] = lcnt;
         }
-        const uint32_t lex = pre[tid] - lcnt;
         __syncthreads();
-        pre[tid] = lex;
-        __syncthreads();
+        block_scan_exclusive<SORT_MAX_FINE>(pre, tmp);
 #pragma unroll
         for (int j = 0; j < FINE_PER; j++)
             if (j * SORT_THREADS + tid < cn) buf[pre[ItemPack<ITEM>::fine(it[j])] + rk[j]] = it[j];
@@ -331,11 +368,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
             if (e < cn) {
                 const ITEM x = buf[e];
                 const uint32_t f = ItemPack<ITEM>::fine(x);
-                sorted[run[f] + (e - pre[f])] = ItemPack<ITEM>::index(x);
+                sorted[run[f] + (e - pre[f])] = ItemPack<ITEM>::entry(x);
             }
         }
         __syncthreads();
     }
+    (void)NF;
 }
 
 // Exclusive scan over K keys in three launches (block partials -> top scan -> final).
@@ -516,7 +554,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_piece_order_kernel(const uin
 // order_tmp: 2 * ORDER_BINS u32
 void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t *out_off, uint32_t K, uint32_t P, uint32_t *order_tmp,
                             uint32_t *perm_t, uint32_t *perm_key, hipStream_t s) {
-    hipMemsetAsync(order_tmp, 0, 8 * ORDER_BINS, s);
+    (void)hipMemsetAsync(order_tmp, 0, 8 * ORDER_BINS, s);
     const uint32_t blocks = (P + SORT_THREADS * ORDER_PER - 1) / (SORT_THREADS * ORDER_PER);
     hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL((msm_piece_order_kernel<false>), dim3(blocks), dim3(SORT_THREADS), 0, s, seg_off, out_off, K, P, order_tmp,
@@ -526,39 +564,43 @@ void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t 
     c.prof_end("msm_piece_order_kernel", pe, s);
 }
 size_t msm_order_tmp_bytes() { return 8 * ORDER_BINS; }
-uint32_t msm_ch() {   // max points per accumulate work-item (LW_HIP_MSM_CH: tuning only)
-    static uint32_t v = [] { const char *e = getenv("LW_HIP_MSM_CH"); int x = e ? atoi(e) : 32; return (uint32_t)(x < 4 ? 4 : (x > 128 ? 128 : x)); }();
-    return v;
+// Max points per accumulate work-item.  With pieces handed out in order of length the cut only has to bound the longest
+// dependent chain: long pieces (64) save partial sums when there is plenty of work (2^24, c = 20: 49.1 ms against 50.0 at
+// 32); when the items do not fill the machine a work-item's chain IS the kernel time, so short pieces and one more
+// round win (2^14, c = 8: 1.60 ms at 16, 2.07 at 64).  LW_HIP_MSM_CH: tuning only.
+uint32_t msm_ch(uint64_t items) {
+    static const int env = [] { const char *e = getenv("LW_HIP_MSM_CH"); return e ? atoi(e) : 0; }();
+    if (env) return (uint32_t)(env < 4 ? 4 : (env > 128 ? 128 : env));
+    return items < (1ull << 22) ? 16u : items < (1ull << 27) ? 32u : 64u;
 }
 int msm_piece_order_enabled() {
     static int v = [] { const char *e = getenv("LW_HIP_MSM_ORDER"); return e ? atoi(e) : 1; }();
     return v;
 }
 
-uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W) {
-    const uint32_t fine = c < SORT_FINE_BITS ? c : SORT_FINE_BITS;
-    return W << (c - fine);
-}
+uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W, uint64_t n) { return W << sort_split(c, n).hb; }
+uint32_t msm_max_window_bits() { return MSM_MAX_C; }
 // row length of the digit matrix: a multiple of 8 (uint4 loads) that is not a power of two, so that the W rows a wave
 // writes do not all fall on the same memory channel
 uint64_t msm_sort_padded_points(uint64_t n) { return ((n + 7) & ~(uint64_t)7) + 1032; }
 template <class ITEM>
-static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t fine, uint32_t CB,
-                          uint16_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
+static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, const SortSplit &sp, uint32_t CB,
+                          uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
                           uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
                           uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
+    const uint32_t fine = sp.fine, hb = sp.hb;
     hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 256 * DIGITS_PER_THREAD - 1) / (256 * DIGITS_PER_THREAD))), dim3(256), 0, s,
                        scalars, n, n_pad, cb, W, dig);
     c.prof_end("msm_digits_kernel", pe, s);
     const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint16_t *)dig, n_pad, cb, fine, coarse_cnt);
+    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, coarse_cnt);
     c.prof_end("msm_coarse_kernel<count>", pe, s);
     msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint16_t *)dig, n_pad, cb, fine,
+    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine,
                        (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
     // level B: sub-blocks of the coarse bins -> key counts -> key offsets (+ the longest bucket) -> sorted index list
@@ -574,18 +616,18 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
                        (const uint32_t *)sub_off, CB, fine, (const uint32_t *)off, key_cursor, sorted);
     c.prof_end("msm_fine_kernel", pe, s);
 }
-// dig: W * padded(n) u16; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off, sub_off: CB + 1; items: n*W u64;
-// key_cnt / key_cursor: K zeroed u32 each; off: K + 1; maxlen: zeroed
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
+// dig: W * padded(n) u32; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off, sub_off: CB + 1; items: n*W u64;
+// key_cnt / key_cursor: K zeroed u32 each; off: K + 1; maxlen: zeroed.  K = W << (cb - 1).
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
-    const uint32_t fine = cb < SORT_FINE_BITS ? cb : SORT_FINE_BITS;
-    const uint32_t CB = W << (cb - fine);
-    if (n <= (1ull << 24))
-        launch_sort_t<uint32_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
+    const SortSplit sp = sort_split(cb, n);
+    const uint32_t CB = W << sp.hb;
+    if (!sp.wide)
+        launch_sort_t<uint32_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
                                 K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, s);
     else
-        launch_sort_t<uint64_t>(c, scalars, n, cb, W, fine, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
+        launch_sort_t<uint64_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
                                 scan_tmp, sub_off, key_cnt, key_cursor, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)

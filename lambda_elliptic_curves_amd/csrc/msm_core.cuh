@@ -9,15 +9,16 @@
 
 namespace lw {
 
-uint32_t msm_ch();                     // max points per accumulate work-item (a bucket is cut into equal pieces <= CH = 32; 64 measured 1 ms slower at 2^24)
+uint32_t msm_ch(uint64_t items);       // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
 int msm_piece_order_enabled();         // LW_HIP_MSM_ORDER=0: work-items take their pieces in key order (A/B)
 uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
 // host launchers for the curve-independent kernels (defined in msm.hip)
-uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W);
+uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W, uint64_t n);
+uint32_t msm_max_window_bits();
 uint64_t msm_sort_padded_points(uint64_t n);
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint16_t *dig, uint32_t *coarse_cnt,
+void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
@@ -36,23 +37,28 @@ template <class C>
 __device__ __forceinline__ void pt_st(void *base, size_t i, const Point<C> &p) { pt_store<C>((char *)base + i * (3 * C::B::BYTES), p); }
 
 // Work-item t sums <= CH items of ONE key.
-//   out_off != nullptr: t is a (key, piece) pair found by binary search in out_off; result -> pout[t]
-//   out_off == nullptr: last round, every key has <= CH items; t is the key; result (identity when the key is
-//                       empty) -> pout[key], the dense bucket array.
-// index != nullptr: item i is the point pts[index[i]] (first round: the caller's points through the sorted index
-// list); otherwise item i is pts[i] (partial sums of the previous round).
+//   out_off != nullptr: t is a (key, piece) pair (key from perm_key or by binary search in out_off).  A key with ONE piece
+//                       is finished by this work-item: its sum goes to buckets[key]; the pieces of a longer key go to
+//                       pout[t] and are summed by the next round.
+//   out_off == nullptr: every key has <= CH items; t is the key; result (identity when the key is empty) -> buckets[key],
+//                       the dense bucket array.
+//   later rounds (index == nullptr) skip keys whose segment is a single partial: an earlier round finished them.
+// index != nullptr: item i is the point +-pts[index[i] & 0x7fffffff], negated when bit 31 is set (first round: the caller's
+// points through the sorted list of signed digits); otherwise item i is pts[i] (partial sums of the previous round).
 // AFFINE: the rows of `pts` are affine pairs of a pre-normalised SRS (lw_hip_srs_*): 2/3 of the bytes per gather and
 // the mixed addition (19 N^2 MACs instead of 21 N^2).  Only first-round launches (index != nullptr) use it.
 template <class C, int WAVES, bool AFFINE>
 __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(const void *pts, const uint32_t *index,
                                                                              const uint32_t *seg_off, const uint32_t *out_off,
                                                                              const uint32_t *perm_t, const uint32_t *perm_key,
-                                                                             uint32_t K, uint32_t total_items, void *pout) {
+                                                                             uint32_t K, uint32_t total_items, void *pout, void *buckets) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= total_items) return;
     // perm_t: pieces in descending order of length (msm_piece_order_kernel), so the lanes of a wave run equally long
     const uint32_t t = perm_t ? perm_t[r] : r;
     uint32_t b, e;
+    void *dst = buckets;
+    size_t slot = t;
     if (out_off) {
         uint32_t lo = 0, hi = K;   // largest key with out_off[key] <= t
         if (perm_key) {
@@ -68,9 +74,12 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
         const uint32_t s0 = seg_off[lo], len = seg_off[lo + 1] - s0, np = out_off[lo + 1] - out_off[lo], j = t - out_off[lo];
         b = s0 + (uint32_t)(((uint64_t)len * j) / np);
         e = s0 + (uint32_t)(((uint64_t)len * (j + 1)) / np);
+        if (!index && len <= 1) return;
+        if (np == 1) slot = lo; else dst = pout;
     } else {
         b = seg_off[t];
         e = seg_off[t + 1];
+        if (!index && e - b <= 1) return;
     }
     // The gather of a point (96-288 B from a random row) is a dependent chain index -> row.  The next index is
     // fetched one addition ahead, and the next row's cache lines are touched (one dword per 128 B, discarded) before
@@ -78,23 +87,28 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
     constexpr int PW = (AFFINE ? 2 : 3) * C::B::BYTES / 4;   // row payload in dwords
     constexpr size_t ROW = AFFINE ? aff_stride<C>() : (size_t)PW * 4;
     auto row_ptr = [&](uint32_t i) { return (const char *)pts + (size_t)i * ROW; };
+    using B = typename C::B;
+    constexpr uint32_t IDX = 0x7fffffffu;
     Point<C> acc = pt_identity<C>();
     uint32_t idx_next = b;
     if (b < e) {
         const uint32_t i0 = index ? index[b] : b;
-        if constexpr (AFFINE) acc = aff_to_point<C>(aff_load<C>(row_ptr(i0)));
-        else acc = pt_load<C>(row_ptr(i0));
+        if constexpr (AFFINE) acc = aff_to_point<C>(aff_load<C>(row_ptr(i0 & IDX)));
+        else acc = pt_load<C>(row_ptr(i0 & IDX));
+        if (index && (i0 >> 31)) acc.y = B::neg(acc.y);
         if (b + 1 < e) idx_next = index ? index[b + 1] : b + 1;
     }
 #pragma nounroll
     for (uint32_t i = b + 1; i < e; i++) {
-        const char *cur = row_ptr(idx_next);
+        const char *cur = row_ptr(idx_next & IDX);
+        const bool neg = index && (idx_next >> 31);
         uint32_t touch0 = 0, touch1 = 0, touch2 = 0;
         if constexpr (AFFINE) {
-            const AffPoint<C> q = aff_load<C>(cur);
+            AffPoint<C> q = aff_load<C>(cur);
+            q.y = B::select(neg, B::neg(q.y), q.y);   // -0 = 0: the identity row (0, 0) stays the identity
             if (i + 1 < e) {
                 idx_next = index ? index[i + 1] : i + 1;
-                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next));
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next & IDX));
                 touch0 = row[0];
                 if constexpr (!(ROW % 128 == 0 && PW * 4 <= 128)) {   // a padded 128-byte row is one line: one touch
                     touch1 = row[32 < PW ? 32 : 0];
@@ -103,10 +117,11 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
             }
             if (!aff_is_identity<C>(q)) acc = pt_add_mixed<C>(acc, q);
         } else {
-            const Point<C> q = pt_load<C>(cur);
+            Point<C> q = pt_load<C>(cur);
+            q.y = B::select(neg, B::neg(q.y), q.y);
             if (i + 1 < e) {
                 idx_next = index ? index[i + 1] : i + 1;
-                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next));
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(row_ptr(idx_next & IDX));
                 touch0 = row[0];
                 touch1 = row[32 < PW ? 32 : 0];
                 touch2 = row[PW - 1];
@@ -115,7 +130,7 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
         }
         asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // consume the touches after the MACs
     }
-    pt_st<C>(pout, t, acc);
+    pt_st<C>(dst, slot, acc);
 }
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
@@ -236,14 +251,20 @@ struct Carver {   // bump allocator over the context workspace
     }
 };
 
-// Window width: a divisor of 256, so that all W windows are full (c = 16: W = 16; c = 8: W = 32).  With c = log2(N) - 4 a
-// short top window (256 mod c bits) put all N items of that window into a handful of keys — one coarse bin, one level-B
-// workgroup — and cost 25-35 % at 2^16..2^20; measured per size with LW_HIP_MSM_C (tools/ab_msm_sizes.py): c = 8 wins below
-// 2^17 (2^16: 2.39 ms against 3.19), c = 16 from there on (2^20: 8.0 ms; c = 15 is within 2 % but only for scalars below 2^255).
+// Window width c (signed digits, W = ceil(257 / c) windows of 2^(c-1) buckets): the bucket additions N * W fall with c, the
+// running sums over W * 2^(c-1) buckets (about three additions per bucket, latency-bound levels) grow with it.  Only widths
+// whose top window is either empty or well filled for 254/255-bit scalars are candidates — c = 8 and 16 (the window at
+// bit 256 holds a carry only for scalars >= 2^255) and c = 20 (15 bits left for the top window); with c = 15, 17 or 18 a
+// top window of 0-3 bits puts N items into a handful of buckets and costs extra rounds (2^22: c = 16 15.6 ms, c = 17
+// 18.9, c = 18 18.3, c = 19 17.1, c = 20 16.5).  Measured with LW_HIP_MSM_C (tools/ab_msm_csweep.sh): 2^14 c = 8 1.60 ms
+// against 1.92 at c = 16; 2^16 2.02 (c = 16) against 2.10; 2^23 c = 20 27.3 against 28.6; 2^24 c = 20 49.1 against 54.8.
 static uint32_t pick_window(size_t n) {
-    static const int c_env = [] { const char *e = getenv("LW_HIP_MSM_C"); return e ? atoi(e) : 0; }();   // tuning only
-    if (c_env >= 4 && c_env <= 16) return (uint32_t)c_env;
-    return n < ((size_t)1 << 17) ? 8u : 16u;
+    const char *e = getenv("LW_HIP_MSM_C");   // tuning and tests only; read per call so a test can sweep it
+    const int c_env = e ? atoi(e) : 0;
+    if (c_env >= 3 && c_env <= (int)msm_max_window_bits()) return (uint32_t)c_env;
+    if (n < ((size_t)1 << 15)) return 8u;
+    if (n < ((size_t)1 << 23)) return 16u;
+    return 20u;
 }
 
 template <class C>
@@ -319,11 +340,11 @@ struct MsmRunner {
     }
 
     // one pass over the pipeline; with cv.base == nullptr it only measures the workspace
-    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, char **S_out,
+    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, char **S_out, char **A_out,
                  uint32_t maxlen_hint) {
-        const uint32_t K = W << cbits;
+        const uint32_t K = W << (cbits - 1);   // signed digits: 2^(c-1) buckets per window, bucket j = multiplier j + 1
         const bool dry = cv.base == nullptr;
-        const uint32_t CB = msm_sort_coarse_bins(cbits, W);
+        const uint32_t CB = msm_sort_coarse_bins(cbits, W, n);
         uint32_t *coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *maxlen_d = (uint32_t *)cv.take(256);
@@ -335,7 +356,7 @@ struct MsmRunner {
         uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
         uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
         uint64_t *items = (uint64_t *)cv.take(8 * n * W);
-        uint16_t *dig = (uint16_t *)cv.take(2 * (size_t)W * msm_sort_padded_points(n));
+        uint32_t *dig = (uint32_t *)cv.take(4 * (size_t)W * msm_sort_padded_points(n));
         uint32_t maxlen = maxlen_hint;
         if (!dry) {
             // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
@@ -347,7 +368,7 @@ struct MsmRunner {
             if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
         }
         // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
-        const uint32_t CH = msm_ch();
+        const uint32_t CH = msm_ch((uint64_t)n * W);
         const bool ordered = msm_piece_order_enabled() != 0;   // first round only: later rounds sum equal numbers of partials
         uint32_t *order_tmp = (uint32_t *)cv.take(msm_order_tmp_bytes());
         const uint32_t *seg = off;
@@ -356,19 +377,20 @@ struct MsmRunner {
         uint64_t len = maxlen;             // longest segment
         uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
         bool first = true;                 // (the dry run has no pointers to tell the rounds apart)
+        char *buckets = (char *)cv.take(PB * (size_t)K);
         auto launch = [&](const uint32_t *out_off, const uint32_t *perm_t, const uint32_t *perm_key, uint32_t total, void *pout,
                           const char *name) {
             const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(stream);
             if (index && affine)
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                   out_off, perm_t, perm_key, K, total, pout);
+                                   out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else if (out_off && C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::ACC_WAVES == 2 ? 3 : C::ACC_WAVES), false>), dim3(blocks), dim3(MSM_THREADS), 0,
-                                   stream, pts, index, seg, out_off, perm_t, perm_key, K, total, pout);
+                                   stream, pts, index, seg, out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
-                                   out_off, perm_t, perm_key, K, total, pout);
+                                   out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             c.prof_end(name, pe, stream);
         };
         while (len > CH) {
@@ -397,17 +419,15 @@ struct MsmRunner {
             len = (len + CH - 1) / CH;
             items_bound = out_bound;
         }
-        char *buckets = (char *)cv.take(PB * (size_t)K);
         {
             const bool ord = ordered && first;
             uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * (size_t)K) : nullptr;
             if (!dry) {
                 if (ord) msm_launch_piece_order(c, seg, nullptr, K, K, order_tmp, perm_t, nullptr, stream);
-                launch(nullptr, perm_t, nullptr, K, (void *)buckets, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
+                launch(nullptr, perm_t, nullptr, K, nullptr, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
             }
         }
-        char *A_unused;
-        return reduce(buckets, 1u << cbits, W, cv, S_out, &A_unused);
+        return reduce(buckets, 1u << (cbits - 1), W, cv, S_out, A_out);
     }
 
     int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {
@@ -417,30 +437,36 @@ struct MsmRunner {
                 set_error("MSM of %zu points: index width is 32 bits", n);
                 return LW_ERR_BAD_ARG;
             }
+            if (n >> 31) {
+                set_error("MSM of %zu points: the sorted list keeps the digit's sign in bit 31 of the index", n);
+                return LW_ERR_BAD_ARG;
+            }
             const uint32_t cbits = pick_window(n);
-            W = (256 + cbits - 1) / cbits;
+            W = (256 + cbits) / cbits;   // ceil(257 / c): the signed recoding of a 256-bit scalar never carries out of the top window
             if (((uint64_t)n * W) >> 32) {
                 set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
                 return LW_ERR_BAD_ARG;
             }
             // size the workspace for the worst case (one bucket holding every point)
             Carver dry{nullptr, 0};
-            char *S_d = nullptr;
-            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, (uint32_t)std::min<size_t>(n, 0xffffffffu));
+            char *S_d = nullptr, *A_d = nullptr;
+            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, &A_d, (uint32_t)std::min<size_t>(n, 0xffffffffu));
             if (rc) return rc;
             if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
             Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};
-            rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, 0);
+            rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, &A_d, 0);
             if (rc) return rc;
             LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
-            std::vector<char> S(PB * W);
+            std::vector<char> S(PB * W), A(PB * W);
             LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, PB * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipMemcpyAsync(A.data(), A_d, PB * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
-            // fold windows most-significant first: acc <- 2^c * acc + S_w  (pippenger.rs:101)
-            result = pt_load<C>(S.data() + PB * (W - 1));
+            // window sum = sum (j + 1) * bucket[j] = S_w + A_w; fold most-significant first: acc <- 2^c * acc + sum_w  (pippenger.rs:101)
+            auto window_sum = [&](uint32_t w) { return pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w)); };
+            result = window_sum(W - 1);
             for (uint32_t w = W - 1; w-- > 0;) {
                 for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
-                result = pt_add<C>(result, pt_load<C>(S.data() + PB * w));
+                result = pt_add<C>(result, window_sum(w));
             }
         }
         result = pt_unmap_result<C>(pt_to_affine<C>(result));

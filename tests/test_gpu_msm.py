@@ -223,3 +223,43 @@ def test_batched_group_law_outer_addition(name):
     for j in range(len(cols)):
         for i in range(len(rows)):
             assert aff(oid, got[j * len(rows) + i]) == aff(oid, O.ec_add(oid, rows[i], cols[j])), (i, j)
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 3000), ("bn254_g1", 1500), ("bn254_g2", 400), ("bls12_381_g2", 300)])
+def test_msm_every_window_width_matches_oracle(name, n, monkeypatch):
+    """The device recodes scalars into SIGNED c-bit digits (msm.hip: |d| <= 2^(c-1), W = ceil(257/c) windows, bucket j =
+    multiplier j + 1) where the reference uses unsigned ones (pippenger.rs:76-81); the sum is the same group element for
+    every c.  LW_HIP_MSM_C forces the width (read per call): all widths the sort supports — narrow and wide items, coarse /
+    fine key splits, windows that start at bit 256 — against the oracle on scalars that exercise the carry chain: random
+    256-bit values (not reduced), 2^256 - 1, 2^255, r - 1, digits equal to exactly half a window, zeros and ones."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    _, points = util.msm_case(oid, n, 900 + n)
+    rng = np.random.default_rng(n)
+    r = D.P_FR381 if name.startswith("bls") else D.P_FR254
+    ks = [int.from_bytes(rng.bytes(32), "big") for _ in range(n)]
+    special = [(1 << 256) - 1, 1 << 255, r - 1, 0, 1, 2, (1 << 255) - 1, 1 << 128, (1 << 128) - 1]
+    for c in range(3, 21):       # every digit of the scalar = 2^(c-1): the largest digit that does not carry; and 2^(c-1) + 1: the smallest that does
+        special.append(sum((1 << (c - 1)) << (c * w) for w in range(256 // c)))
+        special.append(sum(((1 << (c - 1)) + 1) << (c * w) for w in range(256 // c)))
+    for i, v in enumerate(special):
+        ks[(i * 7) % n] = v & ((1 << 256) - 1)
+    scalars = O.ints_to_array(ks, 4)
+    exp = aff(oid, O.parallel_msm_with(oid, scalars, points, 8, 16))
+    for c in range(3, 21):
+        monkeypatch.setenv("LW_HIP_MSM_C", str(c))
+        got = msm.msm(crv, scalars, points)
+        assert aff(oid, got) == exp, f"window width {c}"
+
+
+def test_msm_wide_windows_at_scale_match_oracle(monkeypatch):
+    """c = 20 (the width used from 2^23 points, 64-bit items, 512 coarse bins x 1024 keys) and c = 19 on 2^17 points: buckets of
+    ~0.25 items, the short-top-window path with multi-round partial sums, and the ordered piece dispatch."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 1 << 17
+    scalars, points = util.msm_case(oid, n, 4242, threads=util.host_threads())
+    exp = aff(oid, O.parallel_msm_with(oid, scalars, points, 14, util.host_threads()))
+    for c in (19, 20, 13):
+        monkeypatch.setenv("LW_HIP_MSM_C", str(c))
+        assert aff(oid, msm.msm(crv, scalars, points)) == exp, f"window width {c}"

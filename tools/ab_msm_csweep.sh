@@ -1,0 +1,2 @@
+# usage: ab_msm_csweep.sh "L L ..." "c c ...": MSM wall time (tools/ab_msm_sizes.py) for every window width
+for c in $2; do LW_HIP_MSM_C=$c python tools/ab_msm_sizes.py $1 2>/dev/null | tr '\n' ' '; echo; done
