@@ -136,6 +136,7 @@ void Context::release_all() {
     msm_ws.release();
     msm_scalars.release();
     msm_affine.release();
+    msm_prefix.release();
     shard_a.release();
     shard_b.release();
     if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }

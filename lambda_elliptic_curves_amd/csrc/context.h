@@ -78,6 +78,7 @@ struct Context {
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
     DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
+    DeviceBuf msm_prefix;    // running products of the batch inversion (msm_to_affine_kernel), one base-field element per point
     DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
     hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;

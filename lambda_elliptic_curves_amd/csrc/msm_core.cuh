@@ -135,11 +135,11 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
 // FieldElement::inplace_batch_inverse, field/element.rs:47-65): a work-item walks `chk` points (a strided set, see the kernel), stores the running
-// products of their z in the (not yet final) x slots of the output, inverts the last product once (Fermat), and walks
+// products of their z in a scratch array, inverts the last product once (Fermat), and walks
 // back peeling one inverse per point — 3 products per point plus 1/chk of an inversion instead of a full inversion each.
 // Identity rows (z = 0) are left out of the product and written as (0, 0).
 template <class C>
-__global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, uint32_t chk, void *out) {
+__global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *in, uint64_t n, uint32_t chk, void *out, void *prefix) {
     using B = typename C::B;
     using T = typename B::T;
     constexpr size_t PBY = 3 * B::BYTES, ABY = aff_stride<C>();
@@ -155,13 +155,14 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
     while (cnt < chk && t + (uint64_t)cnt * S < n) cnt++;
     const char *pin = (const char *)in;
     char *pout = (char *)out;
+    char *ppre = (char *)prefix;   // running products, B::BYTES per point: a compact array (whole lines written and read back)
     T acc = B::one();
 #pragma nounroll
     for (uint32_t j = 0; j < cnt; j++) {
         const uint64_t i = t + (uint64_t)j * S;
         const T z = B::load(pin + i * PBY + 2 * B::BYTES);
         if (!B::is_zero(z)) acc = B::mul(acc, z);
-        B::store(pout + i * ABY, acc);            // running product through this work-item's j-th point
+        B::store(ppre + i * B::BYTES, acc);       // running product through this work-item's j-th point
     }
     T inv = B::inv(acc);                          // acc != 0: a product of non-zero field elements (or one)
 #pragma nounroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
             aff_store<C>(pout + i * ABY, AffPoint<C>{B::zero(), B::zero()});
             continue;
         }
-        const T prev = j == 0 ? B::one() : B::load(pout + (i - S) * ABY);
+        const T prev = j == 0 ? B::one() : B::load(ppre + (i - S) * B::BYTES);
         const T zinv = B::mul(inv, prev);         // 1 / z_i
         inv = B::mul(inv, z);                     // 1 / (running product through the previous point)
         const T x = B::load(pin + i * PBY), y = B::load(pin + i * PBY + B::BYTES);
@@ -278,6 +279,7 @@ struct MsmRunner {
     // SRS preparation (lw_hip_srs_create*): n projective rows -> n affine pairs
     int normalize(const void *d_in, size_t n, void *d_out) {
         if (!n) return LW_OK;
+        if (c.msm_prefix.ensure(n * C::B::BYTES)) return LW_ERR_ALLOC;
         hipEvent_t pe = c.prof_begin(stream);
         // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
         // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
@@ -285,7 +287,7 @@ struct MsmRunner {
         const uint32_t chk = chk_env ? chk_env : (n >= ((size_t)1 << 22) ? 128 : 32);
         const uint64_t items = (n + chk - 1) / chk;
         hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
-                           stream, d_in, (uint64_t)n, chk, d_out);
+                           stream, d_in, (uint64_t)n, chk, d_out, c.msm_prefix.p);
         c.prof_end("msm_to_affine_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         return LW_OK;
