@@ -698,8 +698,8 @@ static int msm_normalize_min_log2(lw_curve_t curve) {
     switch (curve) {   // measured break-even (normalise + mixed additions against projective additions)
         case LW_CURVE_BN254_G2: return 18;        // 2^20: 12.3 -> 11.2 ms, 2^21: 18.7 -> 16.6 (mixed addition on the isomorphic curve)
         case LW_CURVE_BLS12_381_G2: return 19;    // 2^20: 24.2 -> 22.6 ms, 2^21: 37.2 -> 34.6; 2^18: 12.7 against 13.4
-        case LW_CURVE_BN254_G1: return 20;        // 2^20: 4.23 -> 4.11 ms
-        default: return 22;                       // BLS12-381 G1: 2^21 12.2 against 12.4, 2^22 and up faster
+        case LW_CURVE_BN254_G1: return 19;        // 2^18: 1.61 against 1.59 ms, 2^19: 2.24 -> 2.15, 2^20: 3.27 -> 3.11
+        default: return 19;                       // BLS12-381 G1: 2^18 2.87 against 2.92 ms, 2^19 4.02 -> 3.90, 2^20 6.10 -> 5.67, 2^21 10.0 -> 9.14
     }
 }
 
