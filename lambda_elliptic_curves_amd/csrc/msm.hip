@@ -64,7 +64,7 @@ void msm_launch_scalar_prep(int bn254, const void *in, void *out, uint64_t n, hi
 // Level B gives every coarse bin to one or more workgroups, which counting-sort it by the low key bits through LDS and
 // emit the per-key offsets the accumulation needs.
 constexpr uint32_t SORT_PPB = 16384;            // points per level-A workgroup (one window)
-constexpr uint32_t SORT_THREADS = 256;
+constexpr uint32_t SORT_THREADS = 512;
 constexpr uint32_t SORT_MAX_COARSE = 512;       // coarse bins per window
 constexpr uint32_t SORT_MAX_FINE = 1024;        // keys per coarse bin
 constexpr uint32_t MSM_MAX_C = 20;              // key bits c - 1 <= 9 + 10

@@ -13,5 +13,5 @@ start = last
 while start > 0 and rows[start - 1][0] > rows[last][0] - 2_000_000:
     start -= 1
 t0 = rows[start][0]
-for s, e, n, q in rows[start:start + 24]:
+for s, e, n, q in rows[start:start + 80]:
     print("%8.3f -> %8.3f  (%7.3f ms)  q%s  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, n))
