@@ -728,6 +728,11 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         // The normalisation reads only the points and the bucket sort only the scalars; both are latency-bound
         // (VALUBusy 34 % and < 20 %), so the normalisation runs on a side stream beside the sort and the main stream
         // joins it just before the first accumulation launch.
+        static const bool side = [] { const char *e = getenv("LW_HIP_MSM_SIDE"); return !e || atoi(e) != 0; }();   // A/B only
+        if (!side) {
+            int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
+            if (rc) return rc;
+        } else {
         if (!c.aux_stream) {
             // lowest priority: the sort on the caller's stream (2.7 ms alone) keeps its pace and the normalisation fills the
             // issue slots it leaves; with equal priorities the sort kernels queued behind the normalisation's workgroups
@@ -751,6 +756,7 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
             LW_HIP_CHECK(hipEventRecord(c.aux_join, c.aux_stream), LW_ERR_LAUNCH);
         }
         join = c.aux_join;
+        }
         d_points = c.msm_affine.p;
         affine_points = 1;
     }
