@@ -25,6 +25,7 @@ struct BbPassParams {
     const void *in;
     void *out;
     const uint32_t *tw;        // T[g] = w^bitrev(g), R = 2^32 domain
+    const uint2 *dd;           // dd[g] = (T[2g] * T[g], -T[2g+1] * T[g]): the composite twiddles of two fused stages
     uint64_t in_batch_stride;  // in memory words
     uint64_t out_batch_stride;
     uint32_t L;                // log2 N (transform length)
@@ -50,7 +51,8 @@ __device__ __forceinline__ void bb_store_word(void *base, uint32_t idx, uint32_t
 }
 
 template <int K, bool LAST, bool IN64>
-__device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const void *gin, uint32_t w,
+__device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const uint32_t *ld1, const uint32_t *ld2,
+                                        const void *gin, uint32_t w,
                                         uint32_t step, uint32_t t0, uint32_t base, uint32_t lgS, uint32_t hi_uniform,
                                         uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
@@ -96,22 +98,66 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             x[j] = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
         }
     }
-    if (!(LW_DBG(p) & 1))
+    // Two stages at a time where the step has them (K = 4: twice), as one radix-4 butterfly whose products are grouped by
+    // output, not by stage: with a, c, b, d = x[j], x[j+q], x[j+2q], x[j+3q], stage twiddle w0 = T[G] and next-stage
+    // twiddles w1 = T[2G], w2 = T[2G+1],
+    //   S = w0 b,  U = w1 c + (w1 w0) d,  V = w2 c - (w2 w0) d,
+    //   a" = (a + S) + U,  c" = (a + S) - U,  b" = (a - S) + V,  d" = (a - S) - V
+    // are exactly the radix-2 results (same canonical residues), but U and V are two-term dot products with ONE
+    // Montgomery reduction each (2 p^2 + 2^32 p < 2^64): 5 v_mad_u64_u32 + 3 reductions + 6 additions = 35 VALU
+    // instructions where two radix-2 stages take 4 x 5 + 8 x 3 = 44.  A 32-bit Montgomery product is dominated by its
+    // reduction (4 of 5 instructions), which is why this pays here and not for the 256-bit fields.  The composite
+    // twiddles w1 w0 and -w2 w0 come from the table dd (same indexing as T).  Non-last passes only (their twiddles are
+    // staged in LDS): in the last pass every work-item fetches its own twiddles from the global tables and the two extra
+    // values per butterfly cost more than the instructions saved (measured: last pass 0.227 -> 0.235 ms, others 0.165 -> 0.150).
+    if (!(LW_DBG(p) & 1)) {
+        int u = 0;
 #pragma unroll
-    for (int u = 0; u < K; u++) {
-        const int half = 1 << (K - 1 - u);
-        const uint32_t gt = (hi_c << (t0 + u)) | (m_high << u);
+        for (; !LAST && u + 1 < K; u += 2) {
+            const int half = 1 << (K - 1 - u), q = half >> 1;
+            const uint32_t gt = (hi_c << (t0 + u)) | (m_high << u);
 #pragma unroll
-        for (int jt = 0; jt < (1 << u); jt++) {
-            // non-last passes: the tile's 2^r - 1 twiddles sit in LDS, stage t group x at slot 2^t - 1 + x
-            const uint32_t tw = LAST ? p.tw[gt | (uint32_t)jt] : ltw[(1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt)];
+            for (int jt = 0; jt < (1 << u); jt++) {
+                uint32_t w0, w1, w2, e1, e2;
+                if (LAST) {
+                    const uint32_t G = gt | (uint32_t)jt;
+                    const uint2 w12 = reinterpret_cast<const uint2 *>(p.tw)[G], e12 = p.dd[G];   // one 8-byte load each
+                    w0 = p.tw[G]; w1 = w12.x; w2 = w12.y; e1 = e12.x; e2 = e12.y;
+                } else {   // the tile's twiddles sit in LDS, stage t group x at slot 2^t - 1 + x
+                    const uint32_t xg = (m_high << u) | (uint32_t)jt;
+                    const uint32_t s0 = (1u << (t0 + u)) - 1 + xg, s1 = (2u << (t0 + u)) - 1 + 2 * xg;
+                    w0 = ltw[s0]; w1 = ltw[s1]; w2 = ltw[s1 + 1]; e1 = ld1[s0]; e2 = ld2[s0];
+                }
 #pragma unroll
-            for (int jl = 0; jl < half; jl++) {
-                const int j = (jt << (K - u)) | jl;
-                const uint32_t wb = bb_mul(tw, x[j + half]);
-                const uint32_t a = x[j];
-                x[j] = bb_add(a, wb);
-                x[j + half] = bb_sub(a, wb);
+                for (int jl = 0; jl < q; jl++) {
+                    const int j = (jt << (K - u)) | jl;
+                    const uint32_t a = x[j], cc = x[j + q], b = x[j + half], d = x[j + half + q];
+                    const uint32_t S = bb_mul(w0, b);
+                    const uint32_t U = bb_reduce((uint64_t)w1 * cc + (uint64_t)e1 * d);
+                    const uint32_t V = bb_reduce((uint64_t)w2 * cc + (uint64_t)e2 * d);
+                    const uint32_t ap = bb_add(a, S), am = bb_sub(a, S);
+                    x[j] = bb_add(ap, U);
+                    x[j + q] = bb_sub(ap, U);
+                    x[j + half] = bb_add(am, V);
+                    x[j + half + q] = bb_sub(am, V);
+                }
+            }
+        }
+#pragma unroll
+        for (; u < K; u++) {   // odd K: one radix-2 stage is left
+            const int half = 1 << (K - 1 - u);
+            const uint32_t gt = (hi_c << (t0 + u)) | (m_high << u);
+#pragma unroll
+            for (int jt = 0; jt < (1 << u); jt++) {
+                const uint32_t tw = LAST ? p.tw[gt | (uint32_t)jt] : ltw[(1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt)];
+#pragma unroll
+                for (int jl = 0; jl < half; jl++) {
+                    const int j = (jt << (K - u)) | jl;
+                    const uint32_t wb = bb_mul(tw, x[j + half]);
+                    const uint32_t a = x[j];
+                    x[j] = bb_add(a, wb);
+                    x[j + half] = bb_sub(a, wb);
+                }
             }
         }
     }
@@ -133,6 +179,7 @@ template <bool LAST, bool IN64, bool OUT64>
 __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     __shared__ uint32_t lds[BB_TILE];
     __shared__ uint32_t ltw[LAST ? 1 : 256];
+    __shared__ uint32_t ld1[LAST ? 1 : 128], ld2[LAST ? 1 : 128];   // composite twiddles of the stages 0 .. r-2
     const uint32_t tid = threadIdx.x;
     const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
     const uint32_t tile_log = r + logC;
@@ -152,6 +199,11 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         for (uint32_t i = tid; i + 1 < (1u << r); i += BB_THREADS) {   // r <= 8: at most 255 twiddles
             const uint32_t t = 31 - __clz(i + 1), xg = i + 1 - (1u << t);
             ltw[i] = p.tw[(hi_uniform << t) | xg];
+            if (t + 1 < r) {
+                const uint2 e12 = p.dd[(hi_uniform << t) | xg];
+                ld1[i] = e12.x;
+                ld2[i] = e12.y;
+            }
         }
         __syncthreads();
     } else {
@@ -164,10 +216,10 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         const bool last_step = (step + 1 == p.nsteps);
         if (step) __syncthreads();
         for (uint32_t w = tid; w < nitems; w += BB_THREADS) {
-            if (k == 4) bb_item<4, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 3) bb_item<3, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else if (k == 2) bb_item<2, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
-            else bb_item<1, LAST, IN64>(p, lds, ltw, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            if (k == 4) bb_item<4, LAST, IN64>(p, lds, ltw, ld1, ld2, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 3) bb_item<3, LAST, IN64>(p, lds, ltw, ld1, ld2, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else if (k == 2) bb_item<2, LAST, IN64>(p, lds, ltw, ld1, ld2, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
+            else bb_item<1, LAST, IN64>(p, lds, ltw, ld1, ld2, gin, w, step, t0, base, lgS, hi_uniform, hi_low, last_step);
         }
         t0 += k;
     }
@@ -189,6 +241,13 @@ __global__ void bb_twiddle_fill_kernel(uint32_t *tw, uint32_t root, uint32_t bit
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= count) return;
     tw[g] = bb_pow(root, bb_bitrev((uint32_t)g, bits));
+}
+
+// composite twiddles of two fused stages (bb_item): dd[g] = (T[2g] * T[g], -T[2g+1] * T[g]), g < count / 2
+__global__ void bb_twiddle_pairs_kernel(const uint32_t *tw, uint2 *dd, uint64_t half_count) {
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= half_count) return;
+    dd[g] = make_uint2(bb_mul(tw[2 * g], tw[g]), bb_sub(0u, bb_mul(tw[2 * g + 1], tw[g])));
 }
 
 // x[i] *= h^i over the transform index i (all V components share the power)
@@ -219,10 +278,12 @@ static int bb_ensure_twiddles(Context &c, lw_dir_t dir, uint32_t log2n, hipStrea
     uint32_t L = log2n < 16 ? 16 : log2n;
     const uint32_t bits = L - 1;
     const uint64_t count = 1ull << bits;
-    if (t.buf.ensure(count * 4)) return LW_ERR_ALLOC;
+    if (t.buf.ensure(count * 8)) return LW_ERR_ALLOC;   // T[count] | dd[count / 2] (pairs)
     const uint32_t w = bb_host_root(L, dir == LW_DIR_INVERSE);
-    hipLaunchKernelGGL(bb_twiddle_fill_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint32_t *)t.buf.p,
-                       w, bits, count);
+    uint32_t *T = (uint32_t *)t.buf.p;
+    hipLaunchKernelGGL(bb_twiddle_fill_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, T, w, bits, count);
+    hipLaunchKernelGGL(bb_twiddle_pairs_kernel, dim3((uint32_t)((count / 2 + 255) / 256)), dim3(256), 0, stream, (const uint32_t *)T,
+                       reinterpret_cast<uint2 *>(T + count), count / 2);
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
     t.log_n = L;
@@ -282,6 +343,10 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         const bool last = (i == npass - 1);
         BbPassParams p{};
         p.tw = (const uint32_t *)c.tw[LW_FIELD_BABYBEAR][dir].buf.p;
+        {
+            const uint64_t tcount = 1ull << (c.tw[LW_FIELD_BABYBEAR][dir].log_n - 1);   // the cached table may be larger than this transform's
+            p.dd = reinterpret_cast<const uint2 *>(p.tw + tcount);
+        }
         p.L = log2n;
         p.lgV = lgV;
         p.dbg = ntt_get_debug();
