@@ -278,7 +278,11 @@ int lw_hip_ec_add_outer_device(lw_curve_t curve, const void *d_rows, size_t m, c
  * the projective points once, normalises them on the device (the to_affine of short_weierstrass/point.rs:91-129; the
  * identity is kept as a marked row) and keeps the affine rows resident; lw_hip_msm_srs then runs the same Pippenger
  * with mixed additions over the first n_scalars points.  Results are identical to lw_hip_msm on the same inputs.
- * n_scalars may be any length <= the SRS length (the KZG call shape); longer is LW_ERR_LENGTH_MISMATCH. */
+ * n_scalars may be any length <= the SRS length (the KZG call shape); longer is LW_ERR_LENGTH_MISMATCH.
+ * Memory: sets of 2^19 points and more keep 13 window-shifted affine copies (2^(20 w) P_i, w = 0..12) so that all windows
+ * of an MSM share one bucket set — 13 x n x {128, 64, 128, 192} bytes for BLS12-381 G1 / BN254 G1 / BN254 G2 /
+ * BLS12-381 G2 (27 GiB at 2^24 BLS12-381 G1 points), built once in lw_hip_srs_create (0.6 s at 2^24) and only while it
+ * fits a quarter of the free device memory; LW_HIP_SRS_FOLD=0 keeps a single copy.  Results do not depend on it. */
 typedef struct lw_srs lw_srs_t;
 int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_srs_t **out_srs);
 int lw_hip_srs_create_device(lw_curve_t curve, const void *d_points, size_t n_points, void *hip_stream, lw_srs_t **out_srs);

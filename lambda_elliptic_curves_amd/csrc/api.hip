@@ -195,6 +195,7 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
                hipStream_t stream, int scalars_montgomery, int affine_points);
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
 size_t msm_affine_bytes(lw_curve_t curve, size_t n);
+int msm_fold_build(Context &c, lw_curve_t curve, void *d_rows, size_t n, uint32_t cbits, hipStream_t stream);
 int ec_add_outer_device(Context &c, lw_curve_t curve, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out,
                         hipStream_t stream);
 int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
@@ -884,7 +885,8 @@ int lw_hip_ec_add_outer_device(lw_curve_t curve, const void *d_rows, size_t m, c
 struct lw_srs {
     lw_curve_t curve;
     size_t n;
-    lw::DeviceBuf pts;   // n affine rows (2 field elements each), (0,0) = identity
+    lw::DeviceBuf pts;   // n affine rows (2 field elements each), (0,0) = identity; folded: W copies, row w * n + i = 2^(c w) P_i
+    uint32_t fold_c = 0; // window width the shifted copies were built for (0: a single copy)
 };
 extern "C" {
 
@@ -893,8 +895,25 @@ static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream
     const size_t pb = lw_hip_curve_point_bytes(curve);
     lw_srs *h = new (std::nothrow) lw_srs{curve, n, {}};
     if (!h) return LW_ERR_ALLOC;
-    if (n && h->pts.ensure(msm_affine_bytes(curve, n))) { delete h; return LW_ERR_ALLOC; }
+    // Large sets keep W = 13 window-shifted copies (c = 20), so that every MSM over them runs its 13 windows into ONE set
+    // of 2^19 buckets (msm_core.cuh build_fold): 13 x the memory of the affine rows — 27 GiB for 2^24 BLS12-381 G1 points,
+    // which is what 288 GB of HBM are for — taken only while it stays below a quarter of the free memory.
+    // LW_HIP_SRS_FOLD=0 keeps the single copy.
+    static const bool fold_env = [] { const char *e = getenv("LW_HIP_SRS_FOLD"); return !e || atoi(e) != 0; }();
+    const uint32_t fold_c = 20, fold_w = (256 + fold_c) / fold_c;
+    const char *fm = getenv("LW_HIP_SRS_FOLD_MIN");   // log2 of the smallest folded set (tests; read per call)
+    const int fold_min = fm ? atoi(fm) : 19;
+    bool fold = fold_env && n >= ((size_t)1 << (fold_min < 0 ? 0 : fold_min > 40 ? 40 : fold_min)) && (((uint64_t)n * fold_w) >> 31) == 0;
+    if (fold) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || msm_affine_bytes(curve, n) * fold_w > free_b / 4) fold = false;
+    }
+    if (n && h->pts.ensure(msm_affine_bytes(curve, n) * (fold ? fold_w : 1))) { delete h; return LW_ERR_ALLOC; }
     int rc = n ? msm_normalize_device(c, curve, d_points, n, h->pts.p, stream) : LW_OK;
+    if (rc == LW_OK && fold) {
+        rc = msm_fold_build(c, curve, h->pts.p, n, fold_c, stream);
+        if (rc == LW_OK) h->fold_c = fold_c;
+    }
     if (rc == LW_OK && n && hipStreamSynchronize(stream) != hipSuccess) { set_error("SRS normalisation failed"); rc = LW_ERR_LAUNCH; }
     if (rc) { h->pts.release(); delete h; return rc; }
     *out_srs = h;
@@ -947,7 +966,15 @@ static int msm_srs_entry(const lw_srs_t *srs, const uint64_t *scalars, size_t n,
         LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
         d_scalars = (const uint64_t *)c.host_io_a.p;
     }
+    // the shifted copies serve calls that use a good part of the set (KZG commits of shorter polynomials take a prefix:
+    // below a quarter of it the 2^19 shared buckets would be mostly empty and the plain schedule on copy 0 is faster)
+    if (srs->fold_c && n >= srs->n / 4) {
+        c.msm_fold_c = srs->fold_c;
+        c.msm_fold_stride = srs->n;
+    }
     rc = msm_device(c, srs->curve, d_scalars, srs->pts.p, n, out_point, stream, mont, 1);
+    c.msm_fold_c = 0;
+    c.msm_fold_stride = 0;
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;

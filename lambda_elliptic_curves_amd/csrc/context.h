@@ -78,6 +78,10 @@ struct Context {
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
     DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
+    // set by the SRS entry points around msm_device, under the entry lock: the point set holds window-shifted copies
+    // (rows w * stride + i = 2^(c w) P_i) and all windows share one bucket set (msm_core.cuh build_fold)
+    uint32_t msm_fold_c = 0;
+    uint64_t msm_fold_stride = 0;
     DeviceBuf msm_prefix;    // running products of the batch inversion (msm_to_affine_kernel), one base-field element per point
     DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
     hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort

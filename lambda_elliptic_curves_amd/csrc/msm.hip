@@ -72,7 +72,7 @@ constexpr uint32_t MSM_MAX_C = 20;              // key bits c - 1 <= 9 + 10
 // split of the c - 1 key bits of a window into (coarse, fine) and the item width.  Narrow items (32 bits: fine digit << 25
 // | sign << 24 | index) halve the traffic of the intermediate list; they fit up to 2^24 points and 7 fine bits.
 struct SortSplit { uint32_t kb, fine, hb; bool wide; };
-static SortSplit sort_split(uint32_t c, uint64_t n) {
+static SortSplit sort_split(uint32_t c, uint64_t n) {   // n: one more than the largest point index an item can carry
     SortSplit sp;
     sp.kb = c - 1;
     sp.wide = n > (1ull << 24) || sp.kb > 15;
@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &v, int e) { return e =
 __device__ __forceinline__ uint32_t coarse_bin(uint32_t enc, uint32_t fine_bits) { return enc ? (((enc >> 1) - 1) >> fine_bits) : SORT_MAX_COARSE; }
 
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
-                                                                       uint32_t *coarse_cnt) {
+                                                                       uint32_t folded, uint32_t *coarse_cnt) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];
     const uint32_t NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
     for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
@@ -198,11 +198,12 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const ui
     }
     __syncthreads();
     for (uint32_t b = tid; b < NB; b += SORT_THREADS)
-        if (h[b]) atomicAdd(&coarse_cnt[(w << hb) + b], h[b]);
+        if (h[b]) atomicAdd(&coarse_cnt[(folded ? 0u : (w << hb)) + b], h[b]);
 }
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
-                                                                 const uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items) {
+                                                                 uint64_t idx_stride, uint32_t folded, const uint32_t *coarse_off,
+                                                                 uint32_t *coarse_cursor, ITEM *items) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
     __shared__ uint32_t base[SORT_MAX_COARSE];    // next free slot of this workgroup's run per bin
     __shared__ uint32_t pre[SORT_MAX_COARSE];     // chunk-local exclusive offsets
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
     __shared__ uint32_t buf[COARSE_CHUNK];
     __shared__ uint16_t bbin[COARSE_CHUNK];       // bin of every staged item
     const uint32_t NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
-    const uint32_t bin0 = w << hb;
+    const uint32_t bin0 = folded ? 0u : (w << hb);   // folded: every window sorts into the one shared bucket set
+    const uint64_t idx0 = (uint64_t)w * idx_stride;      // and its items point at the window's own copy of the points
     for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
     const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
         __syncthreads();
         for (uint32_t e = tid; e < total; e += SORT_THREADS) {
             const uint32_t bin = bbin[e], st = buf[e];
-            items[base[bin] + (e - pre[bin])] = ItemPack<ITEM>::make(st >> 14, (st >> 13) & 1, qc * 4 + (st & 0x1fffu));
+            items[base[bin] + (e - pre[bin])] = ItemPack<ITEM>::make(st >> 14, (st >> 13) & 1, idx0 + qc * 4 + (st & 0x1fffu));
         }
         __syncthreads();
         for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) base[b] += h[b];
@@ -578,7 +580,7 @@ int msm_piece_order_enabled() {
     return v;
 }
 
-uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W, uint64_t n) { return W << sort_split(c, n).hb; }
+uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W, uint64_t n) { return W << sort_split(c, n).hb; }   // folded: W = 1, n = W * stride
 uint32_t msm_max_window_bits() { return MSM_MAX_C; }
 // row length of the digit matrix: a multiple of 8 (uint4 loads) that is not a power of two, so that the W rows a wave
 // writes do not all fall on the same memory channel
@@ -587,8 +589,9 @@ template <class ITEM>
 static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, const SortSplit &sp, uint32_t CB,
                           uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
                           uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
-                          uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
+                          uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
+    const uint32_t folded = fold_stride != 0;
     const uint32_t fine = sp.fine, hb = sp.hb;
     hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 256 * DIGITS_PER_THREAD - 1) / (256 * DIGITS_PER_THREAD))), dim3(256), 0, s,
@@ -596,11 +599,11 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
     c.prof_end("msm_digits_kernel", pe, s);
     const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, coarse_cnt);
+    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, folded, coarse_cnt);
     c.prof_end("msm_coarse_kernel<count>", pe, s);
     msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine,
+    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, fold_stride, folded,
                        (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
     // level B: sub-blocks of the coarse bins -> key counts -> key offsets (+ the longest bucket) -> sorted index list
@@ -620,15 +623,18 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
 // key_cnt / key_cursor: K zeroed u32 each; off: K + 1; maxlen: zeroed.  K = W << (cb - 1).
 void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
-                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s) {
-    const SortSplit sp = sort_split(cb, n);
-    const uint32_t CB = W << sp.hb;
+                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride,
+                     hipStream_t s) {
+    // fold_stride != 0 (lw_hip_srs_* with window-shifted copies of the points): one bucket set of 2^(cb-1) keys for all W
+    // windows; the item of window w and scalar i points at row w * fold_stride + i
+    const SortSplit sp = sort_split(cb, fold_stride ? (uint64_t)W * fold_stride : n);
+    const uint32_t CB = (fold_stride ? 1u : W) << sp.hb;
     if (!sp.wide)
         launch_sort_t<uint32_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
-                                K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, s);
+                                K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
     else
         launch_sort_t<uint64_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
-                                scan_tmp, sub_off, key_cnt, key_cursor, s);
+                                scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {
@@ -667,6 +673,19 @@ size_t msm_affine_bytes_bls12381_g1(size_t n);
 size_t msm_affine_bytes_bn254_g1(size_t n);
 size_t msm_affine_bytes_bn254_g2(size_t n);
 size_t msm_affine_bytes_bls12381_g2(size_t n);
+int msm_fold_build_bls12381_g1(Context &c, hipStream_t s, void *d_rows, size_t n, uint32_t cbits);
+int msm_fold_build_bn254_g1(Context &c, hipStream_t s, void *d_rows, size_t n, uint32_t cbits);
+int msm_fold_build_bn254_g2(Context &c, hipStream_t s, void *d_rows, size_t n, uint32_t cbits);
+int msm_fold_build_bls12381_g2(Context &c, hipStream_t s, void *d_rows, size_t n, uint32_t cbits);
+int msm_fold_build(Context &c, lw_curve_t curve, void *d_rows, size_t n, uint32_t cbits, hipStream_t stream) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_fold_build_bls12381_g1(c, stream, d_rows, n, cbits);
+        case LW_CURVE_BN254_G1: return msm_fold_build_bn254_g1(c, stream, d_rows, n, cbits);
+        case LW_CURVE_BN254_G2: return msm_fold_build_bn254_g2(c, stream, d_rows, n, cbits);
+        case LW_CURVE_BLS12_381_G2: return msm_fold_build_bls12381_g2(c, stream, d_rows, n, cbits);
+        default: return LW_ERR_BAD_ARG;
+    }
+}
 // bytes of the device-resident affine form of n points (rows may be padded, ec.cuh aff_stride)
 size_t msm_affine_bytes(lw_curve_t curve, size_t n) {
     switch (curve) {

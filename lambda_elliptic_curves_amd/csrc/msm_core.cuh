@@ -20,7 +20,8 @@ uint32_t msm_max_window_bits();
 uint64_t msm_sort_padded_points(uint64_t n);
 void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
-                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, hipStream_t s);
+                     uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride,
+                     hipStream_t s);
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
 size_t msm_scan_scratch_bytes(uint32_t K);
 void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t *out_off, uint32_t K, uint32_t P, uint32_t *order_tmp,
@@ -186,6 +187,17 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
     }
 }
 
+// Window-shifted copy of an affine point set (folded SRS): out[i] = 2^c * in[i], projective (normalised by the caller).
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_shift_kernel(const void *aff_in, uint64_t n, uint32_t cbits, void *proj_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Point<C> p = aff_to_point<C>(aff_load<C>((const char *)aff_in + i * aff_stride<C>()));
+#pragma nounroll
+    for (uint32_t k = 0; k < cbits; k++) p = pt_dbl<C>(p);   // complete doubling: the identity row stays the identity
+    pt_st<C>(proj_out, i, p);
+}
+
 // Batched group law (IsGroup::operate_with, short_weierstrass/point.rs:171-207): out[j*m + i] = rows[i] + cols[j].
 // Used to synthesise large sets of distinct points from two short runs (bench inputs: P = [s0 + i*d]G + [j*m*d]G).
 template <class C>
@@ -274,6 +286,8 @@ struct MsmRunner {
     hipStream_t stream;
     uint32_t W;
     bool affine = false;   // d_points are affine pairs (pre-normalised SRS)
+    uint32_t fold_c = 0;        // folded SRS (lw_hip_srs_*): window width the shifted copies were built for, and
+    uint64_t fold_stride = 0;   // rows per copy: d_points[w * fold_stride + i] = 2^(c w) * P_i
     hipEvent_t points_ready = nullptr;   // recorded on a side stream once d_points is complete; joined before the first accumulation
 
     // SRS preparation (lw_hip_srs_create*): n projective rows -> n affine pairs
@@ -294,6 +308,26 @@ struct MsmRunner {
     }
 
     static size_t affine_bytes(size_t n) { return n * aff_stride<C>(); }
+
+    // Folded SRS (lw_hip_srs_*): rows[w * n + i] = 2^(c w) * P_i for w = 1 .. W-1, built from the affine rows 0 .. n-1.
+    // With the 2^(c w) factors in the points, the items of ALL windows can share one set of 2^(c-1) buckets: the running
+    // sums run over 1 window instead of W, which is what lets c = 20 pay from 2^19 points on (HBM is the price: W copies).
+    int build_fold(void *d_rows, size_t n, uint32_t cbits) {
+        const uint32_t Wf = (256 + cbits) / cbits;
+        if (!n) return LW_OK;
+        if (c.msm_affine.ensure(n * PB)) return LW_ERR_ALLOC;   // projective scratch of one copy
+        for (uint32_t w = 1; w < Wf; w++) {
+            const char *prev = (const char *)d_rows + (size_t)(w - 1) * n * aff_stride<C>();
+            hipEvent_t pe = c.prof_begin(stream);
+            hipLaunchKernelGGL((msm_shift_kernel<C>), dim3((uint32_t)((n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, stream,
+                               (const void *)prev, (uint64_t)n, cbits, c.msm_affine.p);
+            c.prof_end("msm_shift_kernel", pe, stream);
+            LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+            int rc = normalize(c.msm_affine.p, n, (char *)d_rows + (size_t)w * n * aff_stride<C>());
+            if (rc) return rc;
+        }
+        return LW_OK;
+    }
     int add_outer(const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) {
         const uint64_t total = (uint64_t)m * k;
         if (!total) return LW_OK;
@@ -344,9 +378,10 @@ struct MsmRunner {
     // one pass over the pipeline; with cv.base == nullptr it only measures the workspace
     int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, char **S_out, char **A_out,
                  uint32_t maxlen_hint) {
-        const uint32_t K = W << (cbits - 1);   // signed digits: 2^(c-1) buckets per window, bucket j = multiplier j + 1
+        const uint32_t NW = fold_stride ? 1u : W;   // bucket sets: one per window, or one for all (folded SRS)
+        const uint32_t K = NW << (cbits - 1);   // signed digits: 2^(c-1) buckets per window, bucket j = multiplier j + 1
         const bool dry = cv.base == nullptr;
-        const uint32_t CB = msm_sort_coarse_bins(cbits, W, n);
+        const uint32_t CB = msm_sort_coarse_bins(cbits, NW, fold_stride ? (uint64_t)W * fold_stride : n);
         uint32_t *coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
         uint32_t *maxlen_d = (uint32_t *)cv.take(256);
@@ -364,7 +399,7 @@ struct MsmRunner {
             // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
             LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
             msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
-                            maxlen_d, scan_tmp, sub_off, key_cnt, key_cursor, stream);
+                            maxlen_d, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, stream);
             LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
@@ -429,7 +464,7 @@ struct MsmRunner {
                 launch(nullptr, perm_t, nullptr, K, nullptr, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
             }
         }
-        return reduce(buckets, 1u << (cbits - 1), W, cv, S_out, A_out);
+        return reduce(buckets, 1u << (cbits - 1), NW, cv, S_out, A_out);
     }
 
     int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {
@@ -443,8 +478,12 @@ struct MsmRunner {
                 set_error("MSM of %zu points: the sorted list keeps the digit's sign in bit 31 of the index", n);
                 return LW_ERR_BAD_ARG;
             }
-            const uint32_t cbits = pick_window(n);
+            const uint32_t cbits = fold_stride ? fold_c : pick_window(n);
             W = (256 + cbits) / cbits;   // ceil(257 / c): the signed recoding of a 256-bit scalar never carries out of the top window
+            if (fold_stride && (((uint64_t)W * fold_stride) >> 31)) {
+                set_error("folded SRS of %llu x %u rows overflows the 31-bit point index", (unsigned long long)fold_stride, W);
+                return LW_ERR_BAD_ARG;
+            }
             if (((uint64_t)n * W) >> 32) {
                 set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
                 return LW_ERR_BAD_ARG;
@@ -459,14 +498,15 @@ struct MsmRunner {
             rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, &A_d, 0);
             if (rc) return rc;
             LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
-            std::vector<char> S(PB * W), A(PB * W);
-            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, PB * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
-            LW_HIP_CHECK(hipMemcpyAsync(A.data(), A_d, PB * W, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            const uint32_t NW = fold_stride ? 1u : W;
+            std::vector<char> S(PB * NW), A(PB * NW);
+            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, PB * NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipMemcpyAsync(A.data(), A_d, PB * NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             // window sum = sum (j + 1) * bucket[j] = S_w + A_w; fold most-significant first: acc <- 2^c * acc + sum_w  (pippenger.rs:101)
             auto window_sum = [&](uint32_t w) { return pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w)); };
-            result = window_sum(W - 1);
-            for (uint32_t w = W - 1; w-- > 0;) {
+            result = window_sum(NW - 1);   // folded: the copies already carry the 2^(c w) factors, one sum is the result
+            for (uint32_t w = NW - 1; w-- > 0;) {
                 for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
                 result = pt_add<C>(result, window_sum(w));
             }
@@ -485,11 +525,17 @@ struct MsmRunner {
             MsmRunner<typename IsoOf<CURVE>::type> ri{c, s, 0};                                                                    \
             ri.affine = true;                                                                                                      \
             ri.points_ready = points_ready;                                                                                        \
+            ri.fold_c = c.msm_fold_c;                                                                                              \
+            ri.fold_stride = c.msm_fold_stride;                                                                                    \
             return ri.run(d_scalars, d_points, n, out);                                                                            \
         }                                                                                                                          \
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         r.affine = affine != 0;                                                                                                    \
         r.points_ready = points_ready;                                                                                             \
+        if (affine) {                                                                                                              \
+            r.fold_c = c.msm_fold_c;                                                                                               \
+            r.fold_stride = c.msm_fold_stride;                                                                                     \
+        }                                                                                                                          \
         return r.run(d_scalars, d_points, n, out);                                                                                 \
     }                                                                                                                              \
     int msm_normalize_##SUFFIX(Context &c, hipStream_t s, const void *d_in, size_t n, void *d_out) {                               \
@@ -497,6 +543,10 @@ struct MsmRunner {
         return r.normalize(d_in, n, d_out);                                                                                        \
     }                                                                                                                              \
     size_t msm_affine_bytes_##SUFFIX(size_t n) { return MsmRunner<CURVE>::affine_bytes(n); }                                      \
+    int msm_fold_build_##SUFFIX(Context &c, hipStream_t s, void *d_rows, size_t n, uint32_t cbits) {   /* rows live on IsoOf<CURVE> */ \
+        MsmRunner<typename IsoOf<CURVE>::type> r{c, s, 0};                                                                         \
+        return r.build_fold(d_rows, n, cbits);                                                                                     \
+    }                                      \
     int ec_add_outer_##SUFFIX(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) { \
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         return r.add_outer(d_rows, m, d_cols, k, d_out);                                                                           \

@@ -127,3 +127,44 @@ def test_srs_identity_rows_across_batch_inversion_runs(name):
     ones[:, 3] = 1                                   # plain sum of the rows: every normalised row is used as is
     assert aff(oid, srs.msm(ones)) == aff(oid, O.msm(oid, ones, points))
     srs.close()
+
+
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 3000), ("bn254_g1", 2000), ("bn254_g2", 700), ("bls12_381_g2", 500)])
+def test_folded_srs_matches_oracle_small(name, n, monkeypatch):
+    """Large SRS handles keep W = 13 window-shifted copies (row w*n + i = 2^(20 w) P_i) and sort the signed 20-bit digits of
+    all windows into ONE set of 2^19 buckets (msm_core.cuh build_fold).  LW_HIP_SRS_FOLD_MIN=0 builds the copies for a small
+    set so the whole path — shift kernel, normalisation of the copies (isomorphic model for BN254 G2), shared buckets, prefix
+    calls above and below the quarter that switches back to the plain schedule, identity rows, adversarial scalars — meets
+    the oracle at a size it finishes instantly."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 1700 + n)
+    r = D.P_FR381 if name.startswith("bls") else D.P_FR254
+    ks = [int(O.limbs_to_int(row)) for row in scalars]
+    for i, v in enumerate([(1 << 256) - 1, 1 << 255, r - 1, 0, 1, (1 << 255) - 1, sum((1 << 19) << (20 * w) for w in range(12)),
+                           sum(((1 << 19) + 1) << (20 * w) for w in range(12))]):
+        ks[(i * 11) % n] = v
+    scalars = O.ints_to_array(ks, 4)
+    points = points.copy()
+    points[5] = O.ec_neutral(oid)              # identity rows must stay the identity in every shifted copy
+    points[n - 1] = O.ec_neutral(oid)
+    points[7] = points[6]                      # repeated point
+    monkeypatch.setenv("LW_HIP_SRS_FOLD_MIN", "0")
+    srs = msm.Srs(crv, points)
+    for m in (n, n - 1, n // 2, n // 4 + 1, n // 5, 3, 0):
+        got = srs.msm(scalars[:m])
+        exp = O.parallel_msm_with(oid, scalars[:m], points[:m], 8, 16) if m else O.ec_neutral(oid)
+        assert aff(oid, got) == aff(oid, exp), f"prefix {m}"
+    srs.close()
+
+
+def test_folded_srs_matches_oracle_at_default_threshold():
+    """2^19 points: the smallest set that is folded by default (BLS12-381 G1), against the oracle."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()["bls12_381_g1"]
+    n = 1 << 19
+    scalars, points = util.msm_case(oid, n, 2024, threads=util.host_threads())
+    srs = msm.Srs(crv, points)
+    exp = aff(oid, O.parallel_msm_with(oid, scalars, points, 15, util.host_threads()))
+    assert aff(oid, srs.msm(scalars)) == exp
+    srs.close()
