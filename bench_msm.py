@@ -228,6 +228,26 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, 
         host_path = {"ms": dth * 1e3, "points_per_s": nh / dth,
                      "what": "lw_hip_msm on host buffers, BLS12-381 G1 2^%d: H2D of %d MiB + MSM" % (Lh, nh * 176 >> 20)}
 
+    srs_path = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        # the shape the reference's callers have (a fixed SRS / proving key, kzg.rs:159-163, groth16 prover.rs:69-85): points
+        # resident and pre-normalised in an lw_hip_srs handle (window-shifted copies from 2^19 points), scalars on the device
+        ts0 = time.perf_counter()
+        srs = msm.Srs(crv, t_points=t_pts, n=n)
+        torch.cuda.synchronize()
+        t_create = time.perf_counter() - ts0
+        got_s = srs.msm_device(t_sc, n)
+        ts0 = time.perf_counter()
+        for _ in range(3):
+            got_s = srs.msm_device(t_sc, n)
+        dts = (time.perf_counter() - ts0) / 3
+        srs.close()
+        same = bool(np.array_equal(np.asarray(got_s), np.asarray(out)))
+        srs_path = {"ms": dts * 1e3, "points_per_s": n / dts, "srs_create_ms": t_create * 1e3, "equals_timed_result": same,
+                    "what": "lw_hip_msm_srs_device over the same 2^%d pairs: lw_hip_srs handle built once, MSM per call" % L}
+        if not same:
+            bit_exact = dict(bit_exact or {}, msm=False, srs_mismatch=True)
+
     acc_names = [k for k in prof if k.startswith("msm_accumulate") or k.startswith("msm_batch")]
     acc_ms = sum(prof[k][1] for k in acc_names)
     dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else ("", (0, 0.0))
@@ -261,5 +281,5 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, 
                  "accumulate_ms_per_msm": acc_ms / steps if acc_ms else None,
                  "valu_busy_pmc": pmc_counter("msm_accumulate", "VALUBusy") or pmc_counter("msm_batch", "VALUBusy")},
         "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
-        "cpu_baseline": cpu, "cpu_all_cores": cpu_all, "bit_exact": bit_exact, "host_path": host_path,
+        "cpu_baseline": cpu, "cpu_all_cores": cpu_all, "bit_exact": bit_exact, "host_path": host_path, "srs_path": srs_path,
     }

@@ -68,7 +68,9 @@ class Srs:
     """A fixed point set kept on the device in affine form (lw_hip_srs_*): what the reference's KZG
     `StructuredReferenceString.powers_main_group` (crypto/src/commitments/kzg.rs:159-163) or a Groth16 proving-key
     vector (provers/groth16/src/prover.rs:69-85) is to repeated msm() calls.  `srs.msm(cs)` equals
-    msm(cs, points[:len(cs)]) — fewer scalars than points is the KZG call shape; more is LengthMismatch."""
+    msm(cs, points[:len(cs)]) — fewer scalars than points is the KZG call shape; more is LengthMismatch.
+    Sets of 2^19 points and more keep 13 window-shifted copies on the device (include/lw_hip.h: 13 x the affine bytes,
+    LW_HIP_SRS_FOLD=0 to keep one); results do not depend on it."""
 
     def __init__(self, curve, points=None, t_points=None, n=None, stream=None):
         self.curve = curve

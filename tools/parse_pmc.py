@@ -4,9 +4,11 @@ into profiles/traffic_latest.json: HBM bytes per launch of the NTT pass kernel (
 kernels of one MSM step ("msm").
 gfx950 corrections: counters are in KiB; FETCH_SIZE reads exactly 1/2 of a wide coalesced stream -> doubled.  The
 guide calibrates that factor for 16-byte-per-lane STREAMING reads and says to calibrate other patterns on a known byte
-count: the MSM accumulation gathers one 128-byte-aligned 128-byte row per item (268 M items at 2^24 = 34.4 GB of lines
-+ 1.07 GB of indices) and its raw FETCH_SIZE reads 35.5 GB, i.e. the counter is exact for whole-line gathers — so
-kernels whose name contains "msm_accumulate" take factor 1, everything else factor 2.
+count: the MSM accumulation gathers one 128-byte-aligned 128-byte row per item (c = 16: 268 M items at 2^24 = 34.4 GB of
+lines + 1.07 GB of indices) and its raw FETCH_SIZE read 35.5 GB when this was calibrated (38-39 GB with the ordered piece
+dispatch; c = 20: 218 M items, 28.8 GB expected, 32.6-33.8 GB read), i.e. the counter is within 15 % of the line count for
+whole-line gathers and nowhere near half of it — so kernels whose name contains "msm_accumulate" take factor 1, everything
+else factor 2.
 usage: parse_pmc.py FETCH_DIR WRITE_DIR NTT_LOG2N MSM_LOG2N MSM_STEPS_TIMED OUT.json"""
 import csv
 import glob
