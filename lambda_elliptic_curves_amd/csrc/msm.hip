@@ -93,9 +93,16 @@ __device__ __forceinline__ void load_scalar_words(const uint32_t *scalars, uint6
 // zeros to n_pad.  The scalar's words are walked with compile-time register indices (a runtime word index would send the
 // eight words through scratch memory: 3.2 ms instead of 0.4 at 2^24).
 constexpr uint32_t DIGITS_PER_THREAD = 8;   // points per work-item: 8192 workgroups at 2^24 instead of 65536 tiny ones
+// When c divides 256 (c = 8, 16) the window at bit 256 would hold nothing but the carry of the one below it: zero for every
+// scalar below 2^255 (all the reference's callers pass representatives below r), but ONE bucket with half of all points
+// for uniform 256-bit scalars.  So the top c-bit window is not recoded: its value u = raw + carry <= 2^c is taken
+// unsigned and split over the last two window slots, u <= 2^(c-1) into slot W-2 (bucket u - 1) and larger values into slot
+// W-1 (bucket u - 2^(c-1) - 1); both slots sit at bit 256 - c and the host fold adds 2^(c-1) times slot W-1's plain sum
+// (msm_core.cuh run()).
 __global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars, uint64_t n, uint64_t n_pad, uint32_t c, uint32_t W,
                                                          uint32_t *dig) {
     const uint32_t mask = (1u << c) - 1, half = 1u << (c - 1);
+    const bool split_top = (W - 1) * c == 256;
     const uint64_t i0 = (uint64_t)blockIdx.x * (256 * DIGITS_PER_THREAD) + threadIdx.x;
 #pragma nounroll
     for (uint32_t q = 0; q < DIGITS_PER_THREAD; q++) {
@@ -108,6 +115,14 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const uint32_t *scalars
         uint32_t *out = dig + i;
         auto emit = [&](uint32_t raw) {
             const uint32_t u = raw + carry;                 // 0 .. 2^c
+            if (split_top && w + 2 == W) {
+                const bool hi = u > half;
+                out[(uint64_t)w * n_pad] = (!hi && u) ? (u << 1) : 0u;
+                out[(uint64_t)(w + 1) * n_pad] = hi ? ((u - half) << 1) : 0u;
+                carry = 0;
+                w += 2;
+                return;
+            }
             const uint32_t neg = u > half;
             const uint32_t m = neg ? (mask + 1 - u) : u;    // |digit| <= 2^(c-1)
             carry = neg;
@@ -139,6 +154,22 @@ template <> struct ItemPack<uint64_t> {
     static __device__ __forceinline__ uint32_t entry(uint64_t it) { return (uint32_t)it; }
 };
 // entry of the sorted list handed to the accumulate kernel: sign << 31 | point index
+// The intermediate list in memory: narrow items as they are; wide items split into the 32-bit entry and the 16-bit fine
+// key (6 bytes written, 2 read by the key count, 6 read by the scatter: 14 bytes per item instead of 24).
+template <class ITEM> struct ItemMem;
+template <> struct ItemMem<uint32_t> {
+    uint32_t *p;
+    __device__ __forceinline__ uint32_t load(uint32_t i) const { return p[i]; }
+    __device__ __forceinline__ uint32_t fine(uint32_t i) const { return p[i] >> 25; }
+    __device__ __forceinline__ void store(uint32_t i, uint32_t it) const { p[i] = it; }
+};
+template <> struct ItemMem<uint64_t> {
+    uint32_t *lo;
+    uint16_t *hi;
+    __device__ __forceinline__ uint64_t load(uint32_t i) const { return ((uint64_t)hi[i] << 32) | lo[i]; }
+    __device__ __forceinline__ uint32_t fine(uint32_t i) const { return hi[i]; }
+    __device__ __forceinline__ void store(uint32_t i, uint64_t it) const { lo[i] = (uint32_t)it; hi[i] = (uint16_t)(it >> 32); }
+};
 
 // exclusive scan of a[0 .. NMAX) in LDS by the whole workgroup (tmp: SORT_THREADS words); returns the total
 template <uint32_t NMAX>
@@ -203,7 +234,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const ui
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
                                                                  uint64_t idx_stride, uint32_t folded, const uint32_t *coarse_off,
-                                                                 uint32_t *coarse_cursor, ITEM *items) {
+                                                                 uint32_t *coarse_cursor, ItemMem<ITEM> items) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
     __shared__ uint32_t base[SORT_MAX_COARSE];    // next free slot of this workgroup's run per bin
     __shared__ uint32_t pre[SORT_MAX_COARSE];     // chunk-local exclusive offsets
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
         __syncthreads();
         for (uint32_t e = tid; e < total; e += SORT_THREADS) {
             const uint32_t bin = bbin[e], st = buf[e];
-            items[base[bin] + (e - pre[bin])] = ItemPack<ITEM>::make(st >> 14, (st >> 13) & 1, idx0 + qc * 4 + (st & 0x1fffu));
+            items.store(base[bin] + (e - pre[bin]), ItemPack<ITEM>::make(st >> 14, (st >> 13) & 1, idx0 + qc * 4 + (st & 0x1fffu)));
         }
         __syncthreads();
         for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) base[b] += h[b];
@@ -301,7 +332,7 @@ __device__ __forceinline__ bool fine_locate(const uint32_t *coarse_off, const ui
 }
 
 template <class ITEM>
-__global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(ItemMem<ITEM> items, const uint32_t *coarse_off, const uint32_t *sub_off,
                                                                      uint32_t CB, uint32_t fine_bits, uint32_t *key_cnt) {
     __shared__ uint32_t h[SORT_MAX_FINE];
     const uint32_t tid = threadIdx.x, NF = 1u << fine_bits;
@@ -310,15 +341,15 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM
     for (uint32_t k = tid; k < NF; k += SORT_THREADS) h[k] = 0;
     __syncthreads();
     for (uint32_t i = i0 + tid; i < i1; i += 8 * SORT_THREADS) {
-        ITEM it[8];
+        uint32_t f[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t k = i + j * SORT_THREADS;
-            it[j] = k < i1 ? items[k] : (ITEM)0;
+            f[j] = k < i1 ? items.fine(k) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (i + j * SORT_THREADS < i1) atomicAdd(&h[ItemPack<ITEM>::fine(it[j])], 1u);
+            if (i + j * SORT_THREADS < i1) atomicAdd(&h[f[j]], 1u);
     }
     __syncthreads();
     for (uint32_t k = tid; k < NF; k += SORT_THREADS)
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_count_kernel(const ITEM
 }
 
 template <class ITEM>
-__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *items, const uint32_t *coarse_off, const uint32_t *sub_off,
+__global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(ItemMem<ITEM> items, const uint32_t *coarse_off, const uint32_t *sub_off,
                                                                uint32_t CB, uint32_t fine_bits, const uint32_t *off, uint32_t *key_cursor,
                                                                uint32_t *sorted) {
     __shared__ uint32_t h[SORT_MAX_FINE];     // chunk-local counts
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_fine_kernel(const ITEM *item
 #pragma unroll
         for (int j = 0; j < FINE_PER; j++) {
             const uint32_t e = j * SORT_THREADS + tid;
-            it[j] = e < cn ? items[c0 + e] : (ITEM)0;
+            it[j] = e < cn ? items.load(c0 + e) : (ITEM)0;
         }
 #pragma unroll
         for (int j = 0; j < FINE_PER; j++)
@@ -587,7 +618,7 @@ uint32_t msm_max_window_bits() { return MSM_MAX_C; }
 uint64_t msm_sort_padded_points(uint64_t n) { return ((n + 7) & ~(uint64_t)7) + 1032; }
 template <class ITEM>
 static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, const SortSplit &sp, uint32_t CB,
-                          uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ITEM *items,
+                          uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ItemMem<ITEM> items,
                           uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
                           uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
@@ -610,12 +641,12 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
     msm_launch_scan(coarse_off, sub_off, CB, (int)FINE_SUB, maxlen + 1, scan_tmp, s);
     const uint32_t UB = CB + (uint32_t)(((uint64_t)n * W + FINE_SUB - 1) / FINE_SUB);   // >= sub_off[CB]; surplus workgroups exit
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_fine_count_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
+    hipLaunchKernelGGL((msm_fine_count_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, items, (const uint32_t *)coarse_off,
                        (const uint32_t *)sub_off, CB, fine, key_cnt);
     c.prof_end("msm_fine_count_kernel", pe, s);
     msm_launch_scan(key_cnt, off, K, 0, maxlen, scan_tmp, s);
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_fine_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, (const ITEM *)items, (const uint32_t *)coarse_off,
+    hipLaunchKernelGGL((msm_fine_kernel<ITEM>), dim3(UB), dim3(SORT_THREADS), 0, s, items, (const uint32_t *)coarse_off,
                        (const uint32_t *)sub_off, CB, fine, (const uint32_t *)off, key_cursor, sorted);
     c.prof_end("msm_fine_kernel", pe, s);
 }
@@ -630,10 +661,11 @@ void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t c
     const SortSplit sp = sort_split(cb, fold_stride ? (uint64_t)W * fold_stride : n);
     const uint32_t CB = (fold_stride ? 1u : W) << sp.hb;
     if (!sp.wide)
-        launch_sort_t<uint32_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, (uint32_t *)items, sorted, off,
-                                K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
-    else
-        launch_sort_t<uint64_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K, maxlen,
+        launch_sort_t<uint32_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, ItemMem<uint32_t>{(uint32_t *)items},
+                                sorted, off, K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
+    else   // the 8 * n * W bytes of `items` hold n * W entries followed by n * W fine keys
+        launch_sort_t<uint64_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor,
+                                ItemMem<uint64_t>{(uint32_t *)items, (uint16_t *)((uint32_t *)items + n * W)}, sorted, off, K, maxlen,
                                 scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)

@@ -505,8 +505,17 @@ struct MsmRunner {
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             // window sum = sum (j + 1) * bucket[j] = S_w + A_w; fold most-significant first: acc <- 2^c * acc + sum_w  (pippenger.rs:101)
             auto window_sum = [&](uint32_t w) { return pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w)); };
-            result = window_sum(NW - 1);   // folded: the copies already carry the 2^(c w) factors, one sum is the result
-            for (uint32_t w = NW - 1; w-- > 0;) {
+            uint32_t top = NW - 1;
+            result = window_sum(top);   // folded: the copies already carry the 2^(c w) factors, one sum is the result
+            if (!fold_stride && (W - 1) * cbits == 256) {
+                // the top window's values above 2^(c-1) live in slot W-1 with 2^(c-1) taken off (msm_digits_kernel): both slots
+                // weigh 2^(256-c); slot W-1 owes 2^(c-1) times its plain sum
+                Point<C> extra = pt_load<C>(A.data() + PB * top);
+                for (uint32_t i = 0; i + 1 < cbits; i++) extra = pt_dbl<C>(extra);
+                top--;
+                result = pt_add<C>(pt_add<C>(result, extra), window_sum(top));
+            }
+            for (uint32_t w = top; w-- > 0;) {
                 for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
                 result = pt_add<C>(result, window_sum(w));
             }
