@@ -220,11 +220,14 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const void *
     // them side by side: the even lane keeps `running`, the odd lane keeps `q` and receives the even lane's value by
     // DPP before each step.  The chain is g additions long instead of 2g.
     using B = typename C::B;
+    // lanes are packed densely over (array, group, role): the small levels have hundreds of arrays with a handful of groups
+    // each, and one workgroup per array left most of every wave idle while the launch took several rounds of workgroups
+    // (n = 8 with 1088 arrays: 0.26 ms for a chain of 4 additions; packed: one round)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t j = t >> 1;
+    const uint32_t pair = t >> 1;
     const bool is_q = t & 1;
-    if (j >= ngroups) return;          // pairs are never split: 2j and 2j+1 leave together
-    const uint32_t w = blockIdx.y;
+    if (pair >= ngroups * nwin) return;          // pairs are never split: 2*pair and 2*pair+1 leave together
+    const uint32_t w = pair / ngroups, j = pair - w * ngroups;
     const size_t base = (size_t)w * n;
     const uint32_t d0 = j * g, d1 = min(n, d0 + g);
     Point<C> acc = pt_identity<C>();
@@ -346,7 +349,8 @@ struct MsmRunner {
             char *out = (char *)cv.take(PB * 2 * (size_t)nwin);
             if (cv.base) {
                 hipEvent_t pe = c.prof_begin(stream);
-                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3(1, nwin), dim3(64), 0, stream, (const void *)in, n, n, 1u, nwin, (void *)out);
+                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((2 * nwin + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
+                                   (const void *)in, n, n, 1u, nwin, (void *)out);
                 c.prof_end("msm_group_sum_kernel", pe, stream);
             }
             *A_out = out;
@@ -357,8 +361,8 @@ struct MsmRunner {
         char *lvl = (char *)cv.take(PB * 2 * (size_t)nwin * ng);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((2 * ng + MSM_THREADS - 1) / MSM_THREADS, nwin), dim3(MSM_THREADS), 0,
-                               stream, (const void *)in, n, g, ng, nwin, (void *)lvl);   // two lanes per group
+            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((uint32_t)((2 * (uint64_t)ng * nwin + MSM_THREADS - 1) / MSM_THREADS)),
+                               dim3(MSM_THREADS), 0, stream, (const void *)in, n, g, ng, nwin, (void *)lvl);   // two lanes per group
             c.prof_end("msm_group_sum_kernel", pe, stream);
         }
         char *S2, *A2;
