@@ -570,12 +570,24 @@ LW_HD Fe<F> fe_neg_raw(const Fe<F> &a) {
     limbs_sub<F::N>(r.v, pk, a.v);
     return r;
 }
+// 2p - a for a < 2p: in (0, 2p], congruent to -a (an unreduced operand of fe_dot, counted as 2 in KSUM)
+template <class F>
+LW_HD Fe<F> fe_neg_raw_2p(const Fe<F> &a) {
+    uint32_t pk[F::N];
+    limbs_kp<F, 1>(pk);
+    Fe<F> r;
+    limbs_sub<F::N>(r.v, pk, a.v);
+    return r;
+}
 // sum_{q<P} a[q]*b[q] * R^-1 mod p, canonical, operands <= p.  One reduction for P products; the result before the
 // final subtraction is < (P*p/R + 1)*p, which must stay below 2p: P*(top limb + 1) <= 2^32 (Fp381: P <= 9, Fp254: P <= 5).
-template <class F, int P>
+// KSUM: bound of sum a[q]*b[q] in units of p^2 — P for reduced operands; more when some are unreduced sums (e.g. an
+// operand below 2p times one below 3p counts 6), as long as KSUM * p / R stays below 1 (Fp381: KSUM <= 9).  Device only.
+template <class F, int P, int KSUM = P>
 LW_HD Fe<F> fe_dot(const Fe<F> *const (&a)[P], const Fe<F> *const (&b)[P]) {
     static_assert(P >= 1 && P <= 4, "fe_dot: 1..4 products");
-    static_assert((uint64_t)P * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32), "fe_dot: sum of products would exceed 2p after reduction");
+    static_assert(KSUM >= P, "fe_dot: KSUM counts every product at least once");
+    static_assert((uint64_t)KSUM * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32), "fe_dot: sum of products would exceed 2p after reduction");
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int N = F::N;
     uint32_t m[N], t[N];
@@ -585,6 +597,7 @@ LW_HD Fe<F> fe_dot(const Fe<F> *const (&a)[P], const Fe<F> *const (&b)[P]) {
     for (int i = 0; i < N; i++) r.v[i] = t[i];
     return reduce_once<F>(r);
 #else
+    static_assert(KSUM == P, "fe_dot: unreduced operands are a device-code feature");
     Fe<F> acc = fe_mul<F>(reduce_once<F>(*a[0]), *b[0]);
     for (int q = 1; q < P; q++) acc = fe_add<F>(acc, fe_mul<F>(reduce_once<F>(*a[q]), *b[q]));
     return acc;

@@ -166,6 +166,15 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
         B::store(ppre + i * B::BYTES, acc);       // running product through this work-item's j-th point
     }
     T inv = B::inv(acc);                          // acc != 0: a product of non-zero field elements (or one)
+    // rows land on the cheaper isomorphic model (L^2 x, L^3 y), see ec.cuh: L^2 rides on the inverse chain (every 1/z_i
+    // peeled off below is then L^2 / z_i, one product per work-item), which leaves x * w and (y * w) * L: three products
+    // per point instead of four
+    T isoL = B::one();
+    if constexpr (IsoOf<C>::has) {
+        using I = typename IsoOf<C>::type;
+        inv = B::mul(inv, I::konst(0));
+        isoL = B::mul(I::konst(1), I::konst(2));   // L = L^3 * L^-2
+    }
 #pragma nounroll
     for (uint32_t j = cnt; j-- > 0;) {
         const uint64_t i = t + (uint64_t)j * S;
@@ -178,9 +187,8 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_to_affine_kernel(const void *
         const T zinv = B::mul(inv, prev);         // 1 / z_i
         inv = B::mul(inv, z);                     // 1 / (running product through the previous point)
         const T x = B::load(pin + i * PBY), y = B::load(pin + i * PBY + B::BYTES);
-        if constexpr (IsoOf<C>::has) {   // rows land on the cheaper isomorphic model: (L^2 x, L^3 y), see ec.cuh
-            using I = typename IsoOf<C>::type;
-            aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(B::mul(x, zinv), I::konst(0)), B::mul(B::mul(y, zinv), I::konst(1))});
+        if constexpr (IsoOf<C>::has) {   // zinv = L^2 / z_i here
+            aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(B::mul(y, zinv), isoL)});
         } else {
             aff_store<C>(pout + i * ABY, AffPoint<C>{B::mul(x, zinv), B::mul(y, zinv)});
         }
