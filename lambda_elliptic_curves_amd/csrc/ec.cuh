@@ -16,6 +16,7 @@ namespace lw {
 template <class F>
 struct FpOps {
     using T = Fe<F>;
+    using Field = F;
     static constexpr int WORDS32 = F::N;
     LW_HD static T add(const T &a, const T &b) { return fe_add<F>(a, b); }
     LW_HD static T sub(const T &a, const T &b) { return fe_sub<F>(a, b); }
@@ -43,7 +44,8 @@ struct FpOps {
 #if defined(__HIP_DEVICE_COMPILE__)
     // Unreduced sums as product operands (fields with headroom only, see fe_dot's KSUM): a + b below 2p for reduced a, b
     // saves the conditional subtraction (24 of 36 instructions at 12 limbs).  K* = bound of the products' sum in p^2.
-    static constexpr bool HEADROOM = (uint64_t)9 * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32);
+    static constexpr bool HEADROOM = (uint64_t)9 * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32);    // Fp381: 2^384 / p = 9.8
+    static constexpr bool HEADROOM5 = (uint64_t)5 * ((uint64_t)F::p(F::N - 1) + 1) <= (1ull << 32);   // Fp254: 2^256 / p = 5.3
     __device__ static T add_nr(const T &a, const T &b) {
         T s;
         limbs_add<F::N>(s.v, a.v, b.v);
@@ -409,10 +411,14 @@ LW_HD Point<C> pt_add_mixed(const Point<C> &p, const AffPoint<C> &q) {
     using B = typename C::B;
     using T = typename B::T;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LW_NO_LAZY_SUMS)
-    if constexpr (std::is_same<B, FpOps<Fp381>>::value) {
-        // Same formula with six of its sums left unreduced where they only feed products (Fp381: 2^384 / p = 9.8, so a
-        // product sum of up to 9 p^2 still reduces to below 2p): (x2 + y2), (x1 + y1), 2 t0, 3 t0, y2 z1 + y1, t1 + 12 z1.
-        // 144 of the addition's ~6150 instructions.  Every output is the canonical residue, as before.
+    if constexpr (std::is_same<B, FpOps<Fp381>>::value || std::is_same<B, FpOps<Fp254>>::value) {
+        // Same formula with some of its sums left unreduced where they only feed products: a product sum of up to K p^2
+        // still reduces to below 2p while K p / R < 1 (fe_dot's KSUM) — Fp381: K <= 9 (2^384 / p = 9.8), six sums:
+        // (x2 + y2), (x1 + y1), 2 t0, 3 t0, y2 z1 + y1, t1 + b3 z1 (144 of the addition's ~6150 instructions); Fp254:
+        // K <= 5, five sums (t1 + b3 z1 stays reduced).  Every output is the canonical residue, as before.
+        static_assert(B::HEADROOM5, "unreduced sums need headroom above 5p");
+        constexpr bool WIDE = B::HEADROOM;
+        using F = typename B::Field;
         T t0 = B::mul(p.x, q.x);
         T t1 = B::mul(p.y, q.y);
         T t3 = B::template mul_k<4>(B::add_nr(q.x, q.y), B::add_nr(p.x, p.y));        // (< 2p)(< 2p)
@@ -421,15 +427,16 @@ LW_HD Point<C> pt_add_mixed(const Point<C> &p, const AffPoint<C> &q) {
         T y3 = B::add(B::mul(q.x, p.z), p.x);
         const T t0x3 = B::add_nr(B::add_nr(t0, t0), t0);                                  // < 3p
         const T t2 = C::mul_b3(p.z);
-        const T z3 = B::add_nr(t1, t2);                                                   // < 2p
+        constexpr int KZ = WIDE ? 2 : 1;
+        const T z3 = WIDE ? B::add_nr(t1, t2) : B::add(t1, t2);                           // < KZ p
         t1 = B::sub(t1, t2);
         constexpr bool B3_IS_2 = std::is_same<C, Bls12381G1Iso>::value;                   // b3 y3 = y3 + y3, left unreduced
         if constexpr (B3_IS_2) y3 = B::add_nr(y3, y3);                                    // < 2p
         else y3 = C::mul_b3(y3);
         constexpr int KY = B3_IS_2 ? 2 : 1;
-        const T xo = B::template dot2_k<1 + 2 * KY>(t3, t1, fe_neg_raw_2p<Fp381>(t4), y3);   // p*p + (2p - t4 <= 2p)*y3
-        const T yo = B::template dot2_k<2 + 3 * KY>(t1, z3, y3, t0x3);                       // p*2p + y3*3p
-        const T zo = B::template dot2_k<7>(z3, t4, t0x3, t3);                                // 2p*2p + 3p*p
+        const T xo = B::template dot2_k<1 + 2 * KY>(t3, t1, fe_neg_raw_2p<F>(t4), y3);    // p*p + (2p - t4 <= 2p)*y3
+        const T yo = B::template dot2_k<KZ + 3 * KY>(t1, z3, y3, t0x3);                   // p*z3 + y3*3p
+        const T zo = B::template dot2_k<2 * KZ + 3>(z3, t4, t0x3, t3);                    // z3*2p + 3p*p
         return Point<C>{xo, yo, zo};
     }
 #endif
