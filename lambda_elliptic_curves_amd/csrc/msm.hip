@@ -3,34 +3,28 @@
 // The reference walks windows sequentially, adding each point into one of 2^c - 1 buckets and folding the
 // buckets with a running sum (pippenger.rs:69-101).  The group element computed here is the same; the
 // schedule is rebuilt for a GPU:
-//   1. digits      every scalar is cut into W = ceil(256/c) unsigned c-bit digits (pippenger.rs:76-77);
-//                  (window, digit) is a bucket key; digit 0 contributes nothing (:78).
-//   2. scatter     counting sort of point indices by key: histogram -> exclusive scan -> scatter
-//                  (all windows in one pass; the order inside a bucket is irrelevant to the group sum).
-//   3. accumulate  segmented reduction over each bucket's index list: every work-item sums <= CH points of
-//                  ONE bucket with the complete addition law (ec.cuh); buckets longer than CH are reduced in
-//                  further rounds, so a skewed scalar distribution (all scalars equal) costs extra rounds,
-//                  not one serial thread.
-//   4. bucket reduce  sum_d d*B[d] per window by a hierarchical running sum: groups of g buckets give
+//   0. normalise   large projective inputs -> affine rows on a side stream (batch inversion; BLS12-381 G1 and BN254 G2
+//                  land on a cheaper isomorphic curve, ec.cuh), so that step 3 uses the mixed addition.
+//   1. digits      every scalar is recoded into W = ceil(257/c) SIGNED c-bit digits (the reference uses unsigned ones,
+//                  pippenger.rs:76-77); (window, |digit| - 1) is a bucket key, the sign negates the point; digit 0
+//                  contributes nothing (:78).  c = 8 / 16 / 20 by size (msm_core.cuh pick_window).
+//   2. scatter     two-level counting sort of (point index, sign) by key through LDS (coarse bins per window, then the
+//                  keys of every coarse bin); the order inside a bucket is irrelevant to the group sum.
+//   3. accumulate  segmented reduction over each bucket's list: every work-item sums one piece (<= CH points) of ONE
+//                  bucket with the complete addition law (ec.cuh), pieces handed out in descending order of length;
+//                  buckets longer than CH are finished in further rounds, so a skewed scalar distribution (all scalars
+//                  equal) costs extra rounds, not one serial thread.
+//   4. bucket reduce  sum_j (j+1)*B[j] per window by a hierarchical running sum: groups of g buckets give
 //                  (A_j, Q_j) = (sum B[d], sum (d-d0) B[d]); then sum_d d*B[d] = sum_j Q_j + g * sum_j j*A_j,
-//                  the second term being the same problem on n/g points.
-//   5. combine     the <= 64 window sums are folded most-significant first, acc <- 2^c * acc + S_w
+//                  the second term being the same problem on n/g points; the window sum is S + A.
+//   5. combine     the <= 33 window sums are folded most-significant first, acc <- 2^c * acc + S_w
 //                  (pippenger.rs:101), on the host with the same limb code, and normalised to (x/z : y/z : 1).
+// lw_hip_srs_* handles of >= 2^19 points keep window-shifted copies of the points, which lets all windows share one
+// bucket set (msm_core.cuh build_fold).
 #include <stdlib.h>
 #include "msm_core.cuh"
 
 namespace lw {
-
-// ---------------------------------------------------------------- digits / sort
-__device__ __forceinline__ uint32_t scalar_word(const uint32_t *s, int j) {   // 32-bit word j, LS first
-    return s[2 * (3 - j / 2) + (j & 1)];
-}
-__device__ __forceinline__ uint32_t scalar_digit(const uint32_t *s, uint32_t w, uint32_t c) {
-    const uint32_t o = w * c, j = o >> 5, sh = o & 31;
-    uint64_t v = scalar_word(s, j);
-    if (j + 1 < 8) v |= (uint64_t)scalar_word(s, j + 1) << 32;
-    return (uint32_t)(v >> sh) & ((1u << c) - 1);
-}
 
 // ---- scalar preparation: FrElement (Montgomery form) -> canonical integer, i.e. `.representative()` --------------
 // Every caller of msm() first maps its witness / coefficients through representative() on the CPU
