@@ -760,9 +760,10 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         d_scalars = (const uint64_t *)c.msm_scalars.p;
     }
-    // Large projective inputs are normalised first (batch inversion, ~5 ms at 2^24) so that the accumulation can use
-    // the mixed addition and 2/3 of the gather bytes (~7.5 ms less at 2^24); below 2^22 the conversion costs more than
-    // it saves.  LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
+    // Large projective inputs are normalised first (batch inversion, ~3 ms at 2^24) so that the accumulation can use
+    // the mixed addition, one-line gathers and — BLS12-381 G1, BN254 G2 — the cheaper isomorphic curve (~10 ms less at
+    // 2^24); below the per-group threshold (msm_normalize_min_log2) the conversion costs more than it saves.
+    // LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
     static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
     hipEvent_t join = nullptr;
     static const int norm_min_env = [] { const char *e = getenv("LW_HIP_MSM_NORM_MIN"); return e ? atoi(e) : -1; }();   // tuning only
@@ -770,9 +771,9 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     if (!affine_points && auto_norm && n >= ((size_t)1 << norm_min_log2)) {
         const size_t aff_bytes = msm_affine_bytes(curve, n);
         if (c.msm_affine.ensure(aff_bytes)) return LW_ERR_ALLOC;
-        // The normalisation reads only the points and the bucket sort only the scalars; both are latency-bound
-        // (VALUBusy 34 % and < 20 %), so the normalisation runs on a side stream beside the sort and the main stream
-        // joins it just before the first accumulation launch.
+        // The normalisation reads only the points and the bucket sort only the scalars, so the normalisation runs on a
+        // side stream beside the sort and the main stream joins it just before the first accumulation launch (both are
+        // memory-bound: side by side they take about the sum of their standalone times less 0.5 ms, LW_HIP_MSM_SIDE).
         static const bool side = [] { const char *e = getenv("LW_HIP_MSM_SIDE"); return !e || atoi(e) != 0; }();   // A/B only
         if (!side) {
             int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
