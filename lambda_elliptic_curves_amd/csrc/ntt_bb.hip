@@ -147,9 +147,23 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
         for (; u < K; u++) {   // odd K: one radix-2 stage is left
             const int half = 1 << (K - 1 - u);
             const uint32_t gt = (hi_c << (t0 + u)) | (m_high << u);
+            // last pass: the 2^u twiddles of this stage are consecutive table entries starting at a multiple of 2^u — one
+            // 8- or 16-byte load (two for u = 3) instead of 2^u dword loads: 5 load instructions per radix-16 step, not 15
+            uint32_t twv[K > 1 ? (1 << (K - 1)) : 2];
+            if (LAST) {
+                if (u == 0) twv[0] = p.tw[gt];
+                else if (u == 1) { const uint2 v = *reinterpret_cast<const uint2 *>(p.tw + gt); twv[0] = v.x; twv[1] = v.y; }
+                else {
+#pragma unroll
+                    for (int q4 = 0; q4 < (1 << u) / 4; q4++) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(p.tw + gt + 4 * q4);
+                        twv[4 * q4] = v.x; twv[4 * q4 + 1] = v.y; twv[4 * q4 + 2] = v.z; twv[4 * q4 + 3] = v.w;
+                    }
+                }
+            }
 #pragma unroll
             for (int jt = 0; jt < (1 << u); jt++) {
-                const uint32_t tw = LAST ? p.tw[gt | (uint32_t)jt] : ltw[(1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt)];
+                const uint32_t tw = LAST ? twv[jt] : ltw[(1u << (t0 + u)) - 1 + ((m_high << u) | (uint32_t)jt)];
 #pragma unroll
                 for (int jl = 0; jl < half; jl++) {
                     const int j = (jt << (K - u)) | jl;
