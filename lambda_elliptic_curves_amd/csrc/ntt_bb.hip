@@ -50,13 +50,17 @@ __device__ __forceinline__ void bb_store_word(void *base, uint32_t idx, uint32_t
     else reinterpret_cast<uint32_t *>(base)[idx] = v;
 }
 
-template <int K, bool LAST, bool IN64>
+// FX: 0 = tile shape from the parameters; 1 / 2 = the full-size tile (r = 8 stages, 32 columns x components, two radix-16
+// steps) with lgV = 0 / 2 as compile-time constants, so that every shift, mask, bit reversal and swizzle of the index
+// arithmetic folds (the passes of every transform of 2^16 words and more; LDS addressing, loads and stores were a quarter
+// of the kernel time with run-time shapes).
+template <int K, bool LAST, bool IN64, int FX = 0>
 __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const uint32_t *ld1, const uint32_t *ld2,
                                         const void *gin, uint32_t w,
                                         uint32_t step, uint32_t t0, uint32_t base, uint32_t lgS, uint32_t hi_uniform,
                                         uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
-    const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
+    const uint32_t r = FX ? 8u : p.r, logC = FX ? 5u : p.logC, L = p.L, lgV = FX == 1 ? 0u : FX == 2 ? 2u : p.lgV;
     const uint32_t logCh = logC - lgV;               // columns proper (distinct tiles in the last pass)
     const uint32_t sh = r - t0 - K;
     // Last pass: work-items walk rows fastest in every step.  In its first step that matches the memory order of the
@@ -189,13 +193,13 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
 // IN64 / OUT64: word type of the pass's source / destination.  Only the caller's buffers hold u64 words (R = 2^64): the
 // intermediate vector between two passes is always written as u32 in the R = 2^32 domain, so a three-pass transform of
 // the u64 shapes moves (8+4) + (4+4) + (4+8) bytes per word instead of 3 x 16.
-template <bool LAST, bool IN64, bool OUT64>
+template <bool LAST, bool IN64, bool OUT64, int FX = 0>
 __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     __shared__ uint32_t lds[BB_TILE];
     __shared__ uint32_t ltw[LAST ? 1 : 256];
     __shared__ uint32_t ld1[LAST ? 1 : 128], ld2[LAST ? 1 : 128];   // composite twiddles of the stages 0 .. r-2
     const uint32_t tid = threadIdx.x;
-    const uint32_t r = p.r, logC = p.logC, L = p.L, lgV = p.lgV;
+    const uint32_t r = FX ? 8u : p.r, logC = FX ? 5u : p.logC, L = p.L, lgV = FX == 1 ? 0u : FX == 2 ? 2u : p.lgV;
     const uint32_t tile_log = r + logC;
     const char *gin = (const char *)p.in + (uint64_t)blockIdx.y * p.in_batch_stride * (IN64 ? 8 : 4);
     char *gout = (char *)p.out + (uint64_t)blockIdx.y * p.out_batch_stride * (OUT64 ? 8 : 4);
@@ -223,6 +227,14 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     } else {
         hi_low = bb_bitrev(b, L - r - (logC - lgV));
     }
+    if constexpr (FX != 0) {   // two radix-16 steps over 512 items, everything about the tile shape known at compile time
+        static_assert(BB_TILE == 16 * 2 * BB_THREADS, "two radix-16 items per work-item and step");
+        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid, 0u, 0u, base, lgS, hi_uniform, hi_low, false);
+        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid + BB_THREADS, 0u, 0u, base, lgS, hi_uniform, hi_low, false);
+        __syncthreads();
+        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid, 1u, 4u, base, lgS, hi_uniform, hi_low, true);
+        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid + BB_THREADS, 1u, 4u, base, lgS, hi_uniform, hi_low, true);
+    } else {
     uint32_t t0 = 0;
     for (uint32_t step = 0; step < p.nsteps; step++) {
         const uint32_t k = p.k[step];
@@ -237,10 +249,10 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         }
         t0 += k;
     }
+    }
     __syncthreads();
-    const uint32_t total = 1u << tile_log;
     const uint32_t logCh = logC - lgV;
-    for (uint32_t e = tid; e < total; e += BB_THREADS) {
+    auto store_one = [&](uint32_t e) {
         const uint32_t c = e & ((1u << logC) - 1);
         const uint32_t m = e >> logC;
         uint32_t g;
@@ -248,6 +260,13 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
         const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
         if (!(LW_DBG(p) & 4)) bb_store_word<OUT64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
+    };
+    if constexpr (FX != 0) {
+#pragma unroll
+        for (int q = 0; q < BB_TILE / BB_THREADS; q++) store_one(tid + (uint32_t)q * BB_THREADS);   // 32 stores, index arithmetic folded
+    } else {
+        const uint32_t total = 1u << tile_log;
+        for (uint32_t e = tid; e < total; e += BB_THREADS) store_one(e);
     }
 }
 
@@ -395,13 +414,22 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         hipEvent_t pe = c.prof_begin(stream);
         // (a 4-columns-per-lane variant of this kernel measured no faster — the pass is bound by butterfly issue and
         // LDS exchange, not by the width of its memory instructions)
+        // full-size tiles (every pass of a transform of 2^16 words and more) take the kernels with the tile shape compiled in
+        const bool full = p.r == 8 && p.logC == 5 && p.nsteps == 2 && p.k[0] == 4 && p.k[1] == 4 && (lgV == 0 || lgV == 2);
+#define LW_BB_LAUNCH(LASTV, INV, OUTV)                                                                                              \
+    do {                                                                                                                            \
+        if (full && lgV == 0) hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 1>), grid, dim3(BB_THREADS), 0, stream, p);      \
+        else if (full) hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 2>), grid, dim3(BB_THREADS), 0, stream, p);             \
+        else hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 0>), grid, dim3(BB_THREADS), 0, stream, p);                       \
+    } while (0)
         if (last) {
-            if (src64) hipLaunchKernelGGL((bb_pass_kernel<true, W64, W64>), grid, dim3(BB_THREADS), 0, stream, p);
-            else hipLaunchKernelGGL((bb_pass_kernel<true, false, W64>), grid, dim3(BB_THREADS), 0, stream, p);
+            if (src64) LW_BB_LAUNCH(true, W64, W64);
+            else LW_BB_LAUNCH(true, false, W64);
         } else {
-            if (src64) hipLaunchKernelGGL((bb_pass_kernel<false, W64, false>), grid, dim3(BB_THREADS), 0, stream, p);
-            else hipLaunchKernelGGL((bb_pass_kernel<false, false, false>), grid, dim3(BB_THREADS), 0, stream, p);
+            if (src64) LW_BB_LAUNCH(false, W64, false);
+            else LW_BB_LAUNCH(false, false, false);
         }
+#undef LW_BB_LAUNCH
         c.prof_end(last ? "bb_pass_kernel<last>" : "bb_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;
