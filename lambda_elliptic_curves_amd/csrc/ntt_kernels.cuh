@@ -119,12 +119,15 @@ __device__ __forceinline__ void lds_wave_sync() {
 // One work-item: 2^K elements, K stages in registers.
 // EXTRA: the pass carries a coset scaling or the N^-1 factor (kept out of the plain transform's code: the last-pass
 // kernel is ~60 KiB of straight-line MAC chains and shares a 64 KiB instruction cache with its neighbour CU)
-template <class F, int K, bool LAST, int TILE, bool EXTRA, bool WL>
+// FX: the full-size tile of the 2048-element configuration (r = 8 stages x 8 columns, four radix-4 steps, one item per
+// work-item and step) with its shape as compile-time constants, so that the shifts, masks, bit reversals and swizzles
+// of the index arithmetic fold (every pass of a 2^24 transform, the last pass from 2^16 on).
+template <class F, int K, bool LAST, int TILE, bool EXTRA, bool WL, bool FX = false>
 __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step, bool stage_tw) {
     constexpr int E = 1 << K;
-    const uint32_t r = p.r, logC = p.logC, L = p.L;
+    const uint32_t r = FX ? 8u : p.r, logC = FX ? 3u : p.logC, L = p.L;
     const uint32_t sh = r - t0 - K;
     uint32_t c, mr;
     if ((LAST && step == 0) || (WL && (LAST || step > 0))) {   // rows fastest: contiguous global rows / one column per wave
@@ -288,7 +291,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     }
 }
 
-template <class F, bool LAST, class CFG, bool EXTRA, bool WL>
+template <class F, bool LAST, class CFG, bool EXTRA, bool WL, bool FX = false>
 __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_kernel(NttPassParams p) {
     constexpr int NTT_THREADS = CFG::THREADS;
     constexpr int NTT_KMAX = CFG::KMAX;
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
     __shared__ uint4 lds[2][NTT_TILE];
     __shared__ uint4 ltw[LAST ? 1 : 2][LAST ? 1 : 256];   // non-last passes: the tile's twiddles (<= 255 x 32 B)
     const uint32_t tid = threadIdx.x;
-    const uint32_t r = p.r, logC = p.logC, L = p.L;
+    static_assert(!FX || (NTT_TILE == 2048 && NTT_THREADS == 512), "FX is the 2^8 x 8 tile with one radix-4 item per work-item");
+    const uint32_t r = FX ? 8u : p.r, logC = FX ? 3u : p.logC, L = p.L;
     const uint32_t tile_log = r + logC;
     const uint4 *gin = p.in + 2 * (uint64_t)blockIdx.y * p.in_batch_stride;
     uint4 *gout = p.out + 2 * (uint64_t)blockIdx.y * p.out_batch_stride;
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
 
     // twiddle staging happens inside the first register step when every thread runs it (the usual case);
     // tiles with fewer items than threads (small transforms) stage up front
-    const bool stage_inside = !LAST && !WL && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS;
+    const bool stage_inside = FX ? (!LAST && !WL)
+                                 : (!LAST && !WL && (1u << (tile_log - p.k[0])) >= (uint32_t)NTT_THREADS && (1u << r) <= (uint32_t)NTT_THREADS);
     if (!LAST && !WL && !stage_inside) {
         // stage t of the pass uses T[(hi << t) | x], x < 2^t, shared by every column of the tile
         for (uint32_t i = tid; i + 1 < (1u << r); i += NTT_THREADS) {
@@ -327,6 +332,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         }
         __syncthreads();
     }
+    if constexpr (FX) {
+#define LW_FX_STEP(S)                                                                                                                  \
+    do {                                                                                                                                \
+        if (S) {                                                                                                                        \
+            if (WL && ((p.wave_sync >> (S)) & 1u)) lds_wave_sync();                                                                     \
+            else __syncthreads();                                                                                                       \
+        }                                                                                                                               \
+        ntt_item<F, 2, LAST, NTT_TILE, EXTRA, WL, true>(p, lds, (uint4 (*)[256])ltw, gin, tid, (S), 2u * (S), base, lgS, hi_uniform,    \
+                                                        hi_low, (S) == 3, stage_inside && (S) == 0);                                    \
+    } while (0)
+        LW_FX_STEP(0u);
+        LW_FX_STEP(1u);
+        LW_FX_STEP(2u);
+        LW_FX_STEP(3u);
+#undef LW_FX_STEP
+    } else {
     uint32_t t0 = 0;
     for (uint32_t step = 0; step < p.nsteps; step++) {
         const uint32_t k = p.k[step];
@@ -343,11 +364,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         }
         t0 += k;
     }
+    }
     __syncthreads();
 
     // coalesced write-out: two lanes per element, 16 B each
-    const uint32_t total = 2u << tile_log;
-    for (uint32_t f = tid; f < total; f += NTT_THREADS) {
+    auto write_one = [&](uint32_t f) {
         const uint32_t e = f >> 1, plane = f & 1;
         const uint32_t c = e & ((1u << logC) - 1);
         const uint32_t m = e >> logC;
@@ -355,6 +376,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         if (!LAST) g = base + ((uint64_t)m << lgS) + c;
         else g = ((uint64_t)bitrev_bits(m, r) << (L - r)) + ((uint64_t)b << logC) + c;
         if (!(LW_DBG(p) & 4)) gout[2 * g + plane] = lds[plane][lds_slot<WL>(m, c, r, logC) ^ (WL ? plane : 0u)];
+    };
+    if constexpr (FX) {
+#pragma unroll
+        for (int q = 0; q < 2 * NTT_TILE / NTT_THREADS; q++) write_one(tid + (uint32_t)q * NTT_THREADS);
+    } else {
+        const uint32_t total = 2u << tile_log;
+        for (uint32_t f = tid; f < total; f += NTT_THREADS) write_one(f);
     }
 }
 
