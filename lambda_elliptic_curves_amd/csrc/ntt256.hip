@@ -184,15 +184,19 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
     q.wave_sync = ws;
 #define LW_LAUNCH_PASS(LASTV, EXTRAV)                                                                                          \
     do {                                                                                                                       \
-        if (fx && wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true, FXOK>), grid, dim3(CFG::THREADS), 0, stream, q);   \
-        else if (fx) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK>), grid, dim3(CFG::THREADS), 0, stream, q);   \
+        if (fx == 8 && wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true, FXOK ? 8 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
+        else if (fx == 8) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK ? 8 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
+        else if (fx == 6 && !wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK ? 6 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
         else if (wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true>), grid, dim3(CFG::THREADS), 0, stream, q);  \
         else hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false>), grid, dim3(CFG::THREADS), 0, stream, q);      \
     } while (0)
-    // full-size tiles (every pass of a 2^24 transform, the last pass from 2^16 on): kernels with the tile shape compiled in
+    // full-size tiles (every pass of a 2^24 transform, the last pass from 2^16 on, the 6-stage passes of 2^20 and 2^26):
+    // kernels with the tile shape compiled in
     constexpr bool FXOK = CFG::TILE == 2048 && CFG::THREADS == 512;
     static const bool fx_env = [] { const char *e = getenv("LW_HIP_NTT_FX"); return !e || atoi(e) != 0; }();   // A/B only
-    const bool fx = FXOK && fx_env && p.r == 8 && p.logC == 3 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 2;
+    int fx = 0;
+    if (FXOK && fx_env && p.r == 8 && p.logC == 3 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 2) fx = 8;
+    if (FXOK && fx_env && p.r == 6 && p.logC == 5 && p.nsteps == 3 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2) fx = 6;   // (6,6,8), (6,6,6,8)
     if (last) {
         if (extra) LW_LAUNCH_PASS(true, true);
         else LW_LAUNCH_PASS(true, false);

@@ -119,15 +119,15 @@ __device__ __forceinline__ void lds_wave_sync() {
 // One work-item: 2^K elements, K stages in registers.
 // EXTRA: the pass carries a coset scaling or the N^-1 factor (kept out of the plain transform's code: the last-pass
 // kernel is ~60 KiB of straight-line MAC chains and shares a 64 KiB instruction cache with its neighbour CU)
-// FX: the full-size tile of the 2048-element configuration (r = 8 stages x 8 columns, four radix-4 steps, one item per
-// work-item and step) with its shape as compile-time constants, so that the shifts, masks, bit reversals and swizzles
+// FX = r: a full-size tile of the 2048-element configuration (r = 8 stages x 8 columns or 6 x 32, r / 2 radix-4 steps, one
+// item per work-item and step) with its shape as compile-time constants, so that the shifts, masks, bit reversals and swizzles
 // of the index arithmetic fold (every pass of a 2^24 transform, the last pass from 2^16 on).
-template <class F, int K, bool LAST, int TILE, bool EXTRA, bool WL, bool FX = false>
+template <class F, int K, bool LAST, int TILE, bool EXTRA, bool WL, int FX = 0>
 __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TILE], uint4 (*ltw)[256], const uint4 *gin,
                                          uint32_t w, uint32_t step, uint32_t t0, uint64_t base, uint32_t lgS,
                                          uint32_t hi_uniform, uint32_t hi_low, bool last_step, bool stage_tw) {
     constexpr int E = 1 << K;
-    const uint32_t r = FX ? 8u : p.r, logC = FX ? 3u : p.logC, L = p.L;
+    const uint32_t r = FX ? (uint32_t)FX : p.r, logC = FX ? (uint32_t)(11 - FX) : p.logC, L = p.L;
     const uint32_t sh = r - t0 - K;
     uint32_t c, mr;
     if ((LAST && step == 0) || (WL && (LAST || step > 0))) {   // rows fastest: contiguous global rows / one column per wave
@@ -291,7 +291,7 @@ __device__ __forceinline__ void ntt_item(const NttPassParams &p, uint4 (*lds)[TI
     }
 }
 
-template <class F, bool LAST, class CFG, bool EXTRA, bool WL, bool FX = false>
+template <class F, bool LAST, class CFG, bool EXTRA, bool WL, int FX = 0>
 __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_kernel(NttPassParams p) {
     constexpr int NTT_THREADS = CFG::THREADS;
     constexpr int NTT_KMAX = CFG::KMAX;
@@ -299,8 +299,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
     __shared__ uint4 lds[2][NTT_TILE];
     __shared__ uint4 ltw[LAST ? 1 : 2][LAST ? 1 : 256];   // non-last passes: the tile's twiddles (<= 255 x 32 B)
     const uint32_t tid = threadIdx.x;
-    static_assert(!FX || (NTT_TILE == 2048 && NTT_THREADS == 512), "FX is the 2^8 x 8 tile with one radix-4 item per work-item");
-    const uint32_t r = FX ? 8u : p.r, logC = FX ? 3u : p.logC, L = p.L;
+    static_assert(!FX || (NTT_TILE == 2048 && NTT_THREADS == 512 && (FX == 8 || FX == 6)), "FX: 2^8 x 8 or 2^6 x 32 rows x columns, one radix-4 item per work-item");
+    const uint32_t r = FX ? (uint32_t)FX : p.r, logC = FX ? (uint32_t)(11 - FX) : p.logC, L = p.L;
     const uint32_t tile_log = r + logC;
     const uint4 *gin = p.in + 2 * (uint64_t)blockIdx.y * p.in_batch_stride;
     uint4 *gout = p.out + 2 * (uint64_t)blockIdx.y * p.out_batch_stride;
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
             if (WL && ((p.wave_sync >> (S)) & 1u)) lds_wave_sync();                                                                     \
             else __syncthreads();                                                                                                       \
         }                                                                                                                               \
-        ntt_item<F, 2, LAST, NTT_TILE, EXTRA, WL, true>(p, lds, (uint4 (*)[256])ltw, gin, tid, (S), 2u * (S), base, lgS, hi_uniform,    \
-                                                        hi_low, (S) == 3, stage_inside && (S) == 0);                                    \
+        ntt_item<F, 2, LAST, NTT_TILE, EXTRA, WL, FX>(p, lds, (uint4 (*)[256])ltw, gin, tid, (S), 2u * (S), base, lgS, hi_uniform,      \
+                                                      hi_low, 2 * ((S) + 1) == FX, stage_inside && (S) == 0);                           \
     } while (0)
         LW_FX_STEP(0u);
         LW_FX_STEP(1u);
         LW_FX_STEP(2u);
-        LW_FX_STEP(3u);
+        if constexpr (FX == 8) LW_FX_STEP(3u);
 #undef LW_FX_STEP
     } else {
     uint32_t t0 = 0;
