@@ -187,6 +187,7 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
         if (fx == 8 && wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true, FXOK ? 8 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
         else if (fx == 8) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK ? 8 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
         else if (fx == 6 && !wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK ? 6 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
+        else if (fx == 7 && !wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false, FXOK ? 7 : 0>), grid, dim3(CFG::THREADS), 0, stream, q);   \
         else if (wl) hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, true>), grid, dim3(CFG::THREADS), 0, stream, q);  \
         else hipLaunchKernelGGL((ntt_pass_kernel<F, LASTV, CFG, EXTRAV, false>), grid, dim3(CFG::THREADS), 0, stream, q);      \
     } while (0)
@@ -196,6 +197,7 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
     static const bool fx_env = [] { const char *e = getenv("LW_HIP_NTT_FX"); return !e || atoi(e) != 0; }();   // A/B only
     int fx = 0;
     if (FXOK && fx_env && p.r == 8 && p.logC == 3 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 2) fx = 8;
+    if (FXOK && fx_env && p.r == 7 && p.logC == 4 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 1) fx = 7;   // (7,7,8)
     if (FXOK && fx_env && p.r == 6 && p.logC == 5 && p.nsteps == 3 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2) fx = 6;   // (6,6,8), (6,6,6,8)
     if (last) {
         if (extra) LW_LAUNCH_PASS(true, true);

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
     __shared__ uint4 lds[2][NTT_TILE];
     __shared__ uint4 ltw[LAST ? 1 : 2][LAST ? 1 : 256];   // non-last passes: the tile's twiddles (<= 255 x 32 B)
     const uint32_t tid = threadIdx.x;
-    static_assert(!FX || (NTT_TILE == 2048 && NTT_THREADS == 512 && (FX == 8 || FX == 6)), "FX: 2^8 x 8 or 2^6 x 32 rows x columns, one radix-4 item per work-item");
+    static_assert(!FX || (NTT_TILE == 2048 && NTT_THREADS == 512 && (FX == 8 || FX == 7 || FX == 6)), "FX: 2^8 x 8, 2^7 x 16 or 2^6 x 32 rows x columns");
     const uint32_t r = FX ? (uint32_t)FX : p.r, logC = FX ? (uint32_t)(11 - FX) : p.logC, L = p.L;
     const uint32_t tile_log = r + logC;
     const uint4 *gin = p.in + 2 * (uint64_t)blockIdx.y * p.in_batch_stride;
@@ -346,6 +346,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::WAVES_PER_SIMD) void ntt_pass_ke
         LW_FX_STEP(1u);
         LW_FX_STEP(2u);
         if constexpr (FX == 8) LW_FX_STEP(3u);
+        if constexpr (FX == 7) {   // the odd stage: a radix-2 step, two items per work-item
+            __syncthreads();
+            ntt_item<F, 1, LAST, NTT_TILE, EXTRA, WL, FX>(p, lds, (uint4 (*)[256])ltw, gin, tid, 3u, 6u, base, lgS, hi_uniform, hi_low, true, false);
+            ntt_item<F, 1, LAST, NTT_TILE, EXTRA, WL, FX>(p, lds, (uint4 (*)[256])ltw, gin, tid + NTT_THREADS, 3u, 6u, base, lgS, hi_uniform, hi_low, true,
+                                                          false);
+        }
 #undef LW_FX_STEP
     } else {
     uint32_t t0 = 0;
