@@ -50,17 +50,17 @@ __device__ __forceinline__ void bb_store_word(void *base, uint32_t idx, uint32_t
     else reinterpret_cast<uint32_t *>(base)[idx] = v;
 }
 
-// FX: 0 = tile shape from the parameters; 1 / 2 = the full-size tile (r = 8 stages, 32 columns x components, two radix-16
-// steps) with lgV = 0 / 2 as compile-time constants, so that every shift, mask, bit reversal and swizzle of the index
-// arithmetic folds (the passes of every transform of 2^16 words and more; LDS addressing, loads and stores were a quarter
-// of the kernel time with run-time shapes).
-template <int K, bool LAST, bool IN64, int FX = 0>
+// RX: 0 = tile shape from the parameters; 8 / 7 / 6 = a full-size tile of r = RX stages x 2^(13 - r) columns x components in
+// two register steps (4+4, 4+3, 3+3 stages) with lgV = VX (0 or 2) — all compile-time constants, so that every shift,
+// mask, bit reversal and swizzle of the index arithmetic folds (every pass of a transform of 2^18 words and more; LDS
+// addressing, loads and stores were a quarter of the kernel time with run-time shapes).
+template <int K, bool LAST, bool IN64, int RX = 0, int VX = 0>
 __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, const uint32_t *ltw, const uint32_t *ld1, const uint32_t *ld2,
                                         const void *gin, uint32_t w,
                                         uint32_t step, uint32_t t0, uint32_t base, uint32_t lgS, uint32_t hi_uniform,
                                         uint32_t hi_low, bool last_step) {
     constexpr int E = 1 << K;
-    const uint32_t r = FX ? 8u : p.r, logC = FX ? 5u : p.logC, L = p.L, lgV = FX == 1 ? 0u : FX == 2 ? 2u : p.lgV;
+    const uint32_t r = RX ? (uint32_t)RX : p.r, logC = RX ? (uint32_t)(BB_TILE_LOG - RX) : p.logC, L = p.L, lgV = RX ? (uint32_t)VX : p.lgV;
     const uint32_t logCh = logC - lgV;               // columns proper (distinct tiles in the last pass)
     const uint32_t sh = r - t0 - K;
     // Last pass: work-items walk rows fastest in every step.  In its first step that matches the memory order of the
@@ -193,13 +193,13 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
 // IN64 / OUT64: word type of the pass's source / destination.  Only the caller's buffers hold u64 words (R = 2^64): the
 // intermediate vector between two passes is always written as u32 in the R = 2^32 domain, so a three-pass transform of
 // the u64 shapes moves (8+4) + (4+4) + (4+8) bytes per word instead of 3 x 16.
-template <bool LAST, bool IN64, bool OUT64, int FX = 0>
+template <bool LAST, bool IN64, bool OUT64, int RX = 0, int VX = 0>
 __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     __shared__ uint32_t lds[BB_TILE];
     __shared__ uint32_t ltw[LAST ? 1 : 256];
     __shared__ uint32_t ld1[LAST ? 1 : 128], ld2[LAST ? 1 : 128];   // composite twiddles of the stages 0 .. r-2
     const uint32_t tid = threadIdx.x;
-    const uint32_t r = FX ? 8u : p.r, logC = FX ? 5u : p.logC, L = p.L, lgV = FX == 1 ? 0u : FX == 2 ? 2u : p.lgV;
+    const uint32_t r = RX ? (uint32_t)RX : p.r, logC = RX ? (uint32_t)(BB_TILE_LOG - RX) : p.logC, L = p.L, lgV = RX ? (uint32_t)VX : p.lgV;
     const uint32_t tile_log = r + logC;
     const char *gin = (const char *)p.in + (uint64_t)blockIdx.y * p.in_batch_stride * (IN64 ? 8 : 4);
     char *gout = (char *)p.out + (uint64_t)blockIdx.y * p.out_batch_stride * (OUT64 ? 8 : 4);
@@ -227,13 +227,23 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
     } else {
         hi_low = bb_bitrev(b, L - r - (logC - lgV));
     }
-    if constexpr (FX != 0) {   // two radix-16 steps over 512 items, everything about the tile shape known at compile time
-        static_assert(BB_TILE == 16 * 2 * BB_THREADS, "two radix-16 items per work-item and step");
-        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid, 0u, 0u, base, lgS, hi_uniform, hi_low, false);
-        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid + BB_THREADS, 0u, 0u, base, lgS, hi_uniform, hi_low, false);
+    if constexpr (RX != 0) {   // two register steps, everything about the tile shape known at compile time
+        static_assert(RX == 8 || RX == 7 || RX == 6, "full-size tiles of 8, 7 or 6 stages");
+        constexpr int K0 = RX >= 7 ? 4 : 3, K1 = RX - K0;
+#define LW_BB_STEP(KK, STEP, T0, LASTSTEP)                                                                                                  \
+    do {                                                                                                                                     \
+        bb_item<KK, LAST, IN64, RX, VX>(p, lds, ltw, ld1, ld2, gin, tid, STEP, T0, base, lgS, hi_uniform, hi_low, LASTSTEP);                 \
+        bb_item<KK, LAST, IN64, RX, VX>(p, lds, ltw, ld1, ld2, gin, tid + BB_THREADS, STEP, T0, base, lgS, hi_uniform, hi_low, LASTSTEP);    \
+        if constexpr (KK == 3) {   /* 2^(13-3) = 1024 items: four per work-item */                                                           \
+            bb_item<KK, LAST, IN64, RX, VX>(p, lds, ltw, ld1, ld2, gin, tid + 2 * BB_THREADS, STEP, T0, base, lgS, hi_uniform, hi_low, LASTSTEP); \
+            bb_item<KK, LAST, IN64, RX, VX>(p, lds, ltw, ld1, ld2, gin, tid + 3 * BB_THREADS, STEP, T0, base, lgS, hi_uniform, hi_low, LASTSTEP); \
+        }                                                                                                                                    \
+    } while (0)
+        static_assert(BB_TILE == 16 * 2 * BB_THREADS, "two radix-16 items (four radix-8 items) per work-item and step");
+        LW_BB_STEP(K0, 0u, 0u, false);
         __syncthreads();
-        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid, 1u, 4u, base, lgS, hi_uniform, hi_low, true);
-        bb_item<4, LAST, IN64, FX>(p, lds, ltw, ld1, ld2, gin, tid + BB_THREADS, 1u, 4u, base, lgS, hi_uniform, hi_low, true);
+        LW_BB_STEP(K1, 1u, (uint32_t)K0, true);
+#undef LW_BB_STEP
     } else {
     uint32_t t0 = 0;
     for (uint32_t step = 0; step < p.nsteps; step++) {
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
         if (!(LW_DBG(p) & 4)) bb_store_word<OUT64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
     };
-    if constexpr (FX != 0) {
+    if constexpr (RX != 0) {
 #pragma unroll
         for (int q = 0; q < BB_TILE / BB_THREADS; q++) store_one(tid + (uint32_t)q * BB_THREADS);   // 32 stores, index arithmetic folded
     } else {
@@ -414,13 +424,20 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         hipEvent_t pe = c.prof_begin(stream);
         // (a 4-columns-per-lane variant of this kernel measured no faster — the pass is bound by butterfly issue and
         // LDS exchange, not by the width of its memory instructions)
-        // full-size tiles (every pass of a transform of 2^16 words and more) take the kernels with the tile shape compiled in
-        const bool full = p.r == 8 && p.logC == 5 && p.nsteps == 2 && p.k[0] == 4 && p.k[1] == 4 && (lgV == 0 || lgV == 2);
+        // full-size tiles (every pass of a transform of 2^18 words and more) take the kernels with the tile shape compiled in
+        const bool full = p.r >= 6 && p.r <= 8 && p.logC == BB_TILE_LOG - p.r && p.nsteps == 2 && p.k[0] == (p.r >= 7 ? 4u : 3u) &&
+                          p.k[1] == p.r - p.k[0] && (lgV == 0 || lgV == 2);
+#define LW_BB_LAUNCH_R(LASTV, INV, OUTV, R)                                                                                          \
+    do {                                                                                                                            \
+        if (lgV == 0) hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, R, 0>), grid, dim3(BB_THREADS), 0, stream, p);            \
+        else hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, R, 2>), grid, dim3(BB_THREADS), 0, stream, p);                     \
+    } while (0)
 #define LW_BB_LAUNCH(LASTV, INV, OUTV)                                                                                              \
     do {                                                                                                                            \
-        if (full && lgV == 0) hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 1>), grid, dim3(BB_THREADS), 0, stream, p);      \
-        else if (full) hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 2>), grid, dim3(BB_THREADS), 0, stream, p);             \
-        else hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 0>), grid, dim3(BB_THREADS), 0, stream, p);                       \
+        if (full && p.r == 8) LW_BB_LAUNCH_R(LASTV, INV, OUTV, 8);                                                                  \
+        else if (full && p.r == 7) LW_BB_LAUNCH_R(LASTV, INV, OUTV, 7);                                                             \
+        else if (full) LW_BB_LAUNCH_R(LASTV, INV, OUTV, 6);                                                                         \
+        else hipLaunchKernelGGL((bb_pass_kernel<LASTV, INV, OUTV, 0, 0>), grid, dim3(BB_THREADS), 0, stream, p);                    \
     } while (0)
         if (last) {
             if (src64) LW_BB_LAUNCH(true, W64, W64);
@@ -430,6 +447,7 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
             else LW_BB_LAUNCH(false, false, false);
         }
 #undef LW_BB_LAUNCH
+#undef LW_BB_LAUNCH_R
         c.prof_end(last ? "bb_pass_kernel<last>" : "bb_pass_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         src = p.out;
