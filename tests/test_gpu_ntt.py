@@ -40,7 +40,7 @@ def test_interpolate_fft_matches_oracle_and_roundtrips(name, log_n):
 
 
 @pytest.mark.parametrize("name", F256)
-@pytest.mark.parametrize("log_n,h", [(3, 3), (6, 7), (10, 3), (13, 2), (17, 7)])
+@pytest.mark.parametrize("log_n,h", [(3, 3), (6, 7), (10, 3), (13, 2), (17, 7), (20, 5), (22, 3)])   # 2^20, 2^22: 6- and 7-stage passes with the coset factor (compiled-in tile shapes)
 def test_offset_variants(name, log_n, h):
     from lambda_elliptic_curves_amd import fft
     fld, oid = _pair(name)
