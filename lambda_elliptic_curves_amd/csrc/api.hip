@@ -137,6 +137,7 @@ void Context::release_all() {
     msm_scalars.release();
     msm_affine.release();
     msm_prefix.release();
+    bb_coset.release();
     shard_a.release();
     shard_b.release();
     if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }

@@ -73,6 +73,7 @@ struct Context {
     int device = -1;
     std::mutex mu;
     TwiddleTable tw[3][2];   // [field][dir]
+    DeviceBuf bb_coset;      // two-level power tables of the current BabyBear coset offset (rebuilt per call: 8192 exponentiations)
     DeviceBuf scratch;
     DeviceBuf small;         // staging for small power tables
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base

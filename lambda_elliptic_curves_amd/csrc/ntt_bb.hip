@@ -34,11 +34,18 @@ struct BbPassParams {
     uint32_t nsteps;
     uint32_t k[8];
     uint32_t scale, sc;        // N^-1 (R = 2^32 domain) on the last pass of an inverse transform
+    // coset transforms (evaluate_offset_fft / interpolate_offset_fft): element i is multiplied by lo[i & mask] * hi[i >> hbits]
+    // = h^i while the first pass loads it (cos_in), or by h^-i * N^-1 while the last pass stores it (cos_out, N^-1 folded into hi)
+    const uint32_t *cos_lo, *cos_hi;
+    uint32_t cos_hbits, cos_in, cos_out;
     uint32_t dbg;              // ablation builds only (-DLW_HIP_ABLATION): bit0 skip butterflies, bit1 skip loads, bit2 skip stores, bit3 old last-pass mapping
 };
 
 __device__ __forceinline__ uint32_t bb_bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
+__device__ __forceinline__ uint32_t bb_coset_factor(const BbPassParams &p, uint32_t i) {
+    return bb_mul(p.cos_lo[i & ((1u << p.cos_hbits) - 1)], p.cos_hi[i >> p.cos_hbits]);
+}
 template <bool W64>
 __device__ __forceinline__ uint32_t bb_load_word(const void *base, uint32_t idx) {
     if (W64) return bb_from_r64(reinterpret_cast<const uint64_t *>(base)[idx]);
@@ -94,6 +101,16 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + (m << lgS) + c;
             x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<IN64>(gin, g);
+        }
+        if (p.cos_in) {   // c_i * h^i, fused into the first pass's load (its own loop: the loads above stay back to back)
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const uint32_t m = mbase | ((uint32_t)j << sh);
+                uint32_t g;
+                if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
+                else g = base + (m << lgS) + c;
+                x[j] = bb_mul(x[j], bb_coset_factor(p, g >> lgV));
+            }
         }
     } else {
 #pragma unroll
@@ -269,7 +286,9 @@ __global__ __launch_bounds__(BB_THREADS) void bb_pass_kernel(BbPassParams p) {
         if (!LAST) g = base + (m << lgS) + c;
         else g = (((bb_bitrev(m, r) << (L - r)) + (b << logCh) + (c >> lgV)) << lgV) | (c & ((1u << lgV) - 1));
         const uint32_t swz = (LAST && !(LW_DBG(p) & 8)) ? ((1u << logC) - 1) : 0u;   // same slot mapping as bb_item
-        if (!(LW_DBG(p) & 4)) bb_store_word<OUT64>(gout, g, lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))]);
+        uint32_t v = lds[(m << logC) | (c ^ ((m ^ (m >> 4)) & swz))];
+        if (p.cos_out) v = bb_mul(v, bb_coset_factor(p, g >> lgV));   // h^-i * N^-1, fused into the last pass's store
+        if (!(LW_DBG(p) & 4)) bb_store_word<OUT64>(gout, g, v);
     };
     if constexpr (RX != 0) {
 #pragma unroll
@@ -293,16 +312,11 @@ __global__ void bb_twiddle_pairs_kernel(const uint32_t *tw, uint2 *dd, uint64_t 
     dd[g] = make_uint2(bb_mul(tw[2 * g], tw[g]), bb_sub(0u, bb_mul(tw[2 * g + 1], tw[g])));
 }
 
-// x[i] *= h^i over the transform index i (all V components share the power)
-template <bool IN64, bool OUT64>
-__global__ void bb_scale_powers_kernel(const void *in, void *out, uint32_t h, uint32_t lgV, uint64_t nwords,
-                                       uint64_t in_batch_stride, uint64_t out_batch_stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nwords) return;
-    const char *gin = (const char *)in + (uint64_t)blockIdx.y * in_batch_stride * (IN64 ? 8 : 4);
-    char *gout = (char *)out + (uint64_t)blockIdx.y * out_batch_stride * (OUT64 ? 8 : 4);
-    uint32_t pw = bb_pow(h, i >> lgV);
-    bb_store_word<OUT64>(gout, i, bb_mul(bb_load_word<IN64>(gin, i), pw));
+// two-level power tables of a coset offset: lo[j] = h^j (j < 2^hbits), hi[j] = scale * h^(j << hbits) (j < n_hi)
+__global__ void bb_power_tables_kernel(uint32_t *lo, uint32_t *hi, uint32_t h, uint32_t hbits, uint32_t n_hi, uint32_t scale) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (1u << hbits)) lo[t] = bb_pow(h, t);
+    if (t < n_hi) hi[t] = bb_mul(scale, bb_pow(h, (uint64_t)t << hbits));
 }
 
 // ---------------------------------------------------------------- host
@@ -360,21 +374,28 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
     const uint32_t max_r = 8;
     int npass = (int)((log2n + max_r - 1) / max_r);
     if (npass < 1) npass = 1;
-    const bool need_scratch = npass > 1 || d_in == d_out || (coset && dir == LW_DIR_FORWARD);
+    const bool need_scratch = npass > 1 || d_in == d_out;
     if (need_scratch && c.scratch.ensure((size_t)nwords * batch * wbytes)) return LW_ERR_ALLOC;
+    // coset factors: h^i fused into the first pass's load (forward), h^-i * N^-1 into the last pass's store (inverse) —
+    // a separate kernel with one exponentiation per element cost more than the transform (0.59 ms against 0.48 at 4 x 2^24)
+    const uint32_t cos_hbits = log2n < 12 ? log2n : 12, cos_nhi = 1u << (log2n - cos_hbits);
+    uint32_t *cos_lo = nullptr, *cos_hi = nullptr;
+    if (coset) {
+        if (c.bb_coset.ensure(4 * ((size_t)(1u << cos_hbits) + cos_nhi))) return LW_ERR_ALLOC;
+        cos_lo = (uint32_t *)c.bb_coset.p;
+        cos_hi = cos_lo + (1u << cos_hbits);
+        const bool inv = dir == LW_DIR_INVERSE;
+        const uint32_t base_h = inv ? bb_inv(h) : h;
+        const uint32_t hi_scale = inv ? bb_inv(bb_mul((uint32_t)(n % BabyBear::P), BabyBear::R2)) : BabyBear::ONE;
+        const uint32_t cnt = (1u << cos_hbits) > cos_nhi ? (1u << cos_hbits) : cos_nhi;
+        hipLaunchKernelGGL(bb_power_tables_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, cos_lo, cos_hi, base_h, cos_hbits, cos_nhi,
+                           hi_scale);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    }
 
     const void *src = d_in;
     uint64_t src_stride = stride;
     bool src64 = W64;   // word type of `src`: the layout's in the caller's buffers, u32 in every intermediate this function writes
-    if (coset && dir == LW_DIR_FORWARD) {
-        dim3 grid((uint32_t)((nwords + 255) / 256), batch);
-        hipEvent_t pe = c.prof_begin(stream);
-        hipLaunchKernelGGL((bb_scale_powers_kernel<W64, false>), grid, dim3(256), 0, stream, d_in, c.scratch.p, h, lgV, nwords, stride, nwords);
-        c.prof_end("bb_scale_powers_kernel", pe, stream);
-        src = c.scratch.p;
-        src_stride = nwords;
-        src64 = false;
-    }
     if (npass == 1 && src == d_out) {
         LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, nwords * wbytes, d_in, stride * wbytes, nwords * wbytes, batch,
                                       hipMemcpyDeviceToDevice, stream), LW_ERR_LAUNCH);
@@ -407,11 +428,16 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         }
         p.in = src;
         p.in_batch_stride = src_stride;
+        p.cos_lo = cos_lo;
+        p.cos_hi = cos_hi;
+        p.cos_hbits = cos_hbits;
+        p.cos_in = (coset && dir == LW_DIR_FORWARD && i == 0) ? 1u : 0u;
+        p.cos_out = (coset && dir == LW_DIR_INVERSE && last) ? 1u : 0u;
         if (last) {
             if (src == d_out) { set_error("internal: last NTT pass would run in place"); return LW_ERR_BAD_ARG; }
             p.out = d_out;
             p.out_batch_stride = stride;
-            if (dir == LW_DIR_INVERSE) {
+            if (dir == LW_DIR_INVERSE && !coset) {   // with a coset offset N^-1 rides in the hi table
                 p.scale = 1;
                 p.sc = bb_inv(bb_mul((uint32_t)(n % BabyBear::P), BabyBear::R2));   // FieldElement::from(n).inv()
             }
@@ -454,12 +480,6 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         src_stride = p.out_batch_stride;
         src64 = last ? W64 : false;
         s += p.r;
-    }
-    if (coset && dir == LW_DIR_INVERSE) {
-        dim3 grid((uint32_t)((nwords + 255) / 256), batch);
-        hipEvent_t pe = c.prof_begin(stream);
-        hipLaunchKernelGGL((bb_scale_powers_kernel<W64, W64>), grid, dim3(256), 0, stream, d_out, d_out, bb_inv(h), lgV, nwords, stride, stride);
-        c.prof_end("bb_scale_powers_kernel", pe, stream);
     }
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     return LW_OK;
