@@ -22,28 +22,43 @@ __constant__ uint64_t KECCAK_RC[24] = {
     0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
     0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// Keccak-f[1600] on explicit 32-bit halves: a 64-bit rotation by a constant is two v_alignbit_b32, chi's a ^ (~b & c) one
+// v_bitop3_b32 per half and theta's column parities three-input XORs (written on uint64_t the compiler emitted 64-bit
+// shift pairs and v_bfi + v_xor: ~300 instructions per round against ~190 here).
+struct U64H { uint32_t lo, hi; };
+__device__ __forceinline__ U64H rotl64h(U64H x, int n) {   // n: compile-time constant, 1 .. 63
+    if (n == 32) return U64H{x.hi, x.lo};
+    if (n < 32) return U64H{__builtin_amdgcn_alignbit(x.lo, x.hi, 32 - n), __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - n)};
+    return U64H{__builtin_amdgcn_alignbit(x.hi, x.lo, 64 - n), __builtin_amdgcn_alignbit(x.lo, x.hi, 64 - n)};
+}
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }   // a ^ b ^ c
 
-__device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25]) {
+__device__ __forceinline__ void keccak_f1600(uint64_t (&st)[25]) {
     constexpr int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
     constexpr int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    U64H a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = U64H{(uint32_t)st[i], (uint32_t)(st[i] >> 32)};
 #pragma unroll 1
     for (int round = 0; round < 24; round++) {
-        uint64_t bc[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) bc[i] = a[i] ^ a[i + 5] ^ a[i + 10] ^ a[i + 15] ^ a[i + 20];
+        U64H bc[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            const uint64_t t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
-#pragma unroll
-            for (int j = 0; j < 25; j += 5) a[j + i] ^= t;
+            bc[i].lo = xor3(xor3(a[i].lo, a[i + 5].lo, a[i + 10].lo), a[i + 15].lo, a[i + 20].lo);
+            bc[i].hi = xor3(xor3(a[i].hi, a[i + 5].hi, a[i + 10].hi), a[i + 15].hi, a[i + 20].hi);
         }
-        uint64_t t = a[1];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const U64H u = bc[(i + 4) % 5], v = rotl64h(bc[(i + 1) % 5], 1);
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) a[j + i] = U64H{xor3(a[j + i].lo, u.lo, v.lo), xor3(a[j + i].hi, u.hi, v.hi)};
+        }
+        U64H t = a[1];
 #pragma unroll
         for (int i = 0; i < 24; i++) {
             const int j = PIL[i];
-            const uint64_t b = a[j];
-            a[j] = rotl64(t, ROT[i]);
+            const U64H b = a[j];
+            a[j] = rotl64h(t, ROT[i]);
             t = b;
         }
 #pragma unroll
@@ -51,10 +66,17 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25]) {
 #pragma unroll
             for (int i = 0; i < 5; i++) bc[i] = a[j + i];
 #pragma unroll
-            for (int i = 0; i < 5; i++) a[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+            for (int i = 0; i < 5; i++) {
+                a[j + i].lo = bc[i].lo ^ (~bc[(i + 1) % 5].lo & bc[(i + 2) % 5].lo);
+                a[j + i].hi = bc[i].hi ^ (~bc[(i + 1) % 5].hi & bc[(i + 2) % 5].hi);
+            }
         }
-        a[0] ^= KECCAK_RC[round];
+        const uint64_t rc = KECCAK_RC[round];
+        a[0].lo ^= (uint32_t)rc;
+        a[0].hi ^= (uint32_t)(rc >> 32);
     }
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = ((uint64_t)a[i].hi << 32) | a[i].lo;
 }
 
 // one work-item per leaf; columns[c] starts at cols + c * col_stride elements (4 u64 limbs each, reference layout)
