@@ -127,6 +127,32 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(uint64_t *nodes, uint
     out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
 }
 
+// The top of the tree in one launch: all levels from `count` <= 256 parents down to the root, one workgroup, a barrier
+// between levels (a launch per level spends ~18 us on a kernel that hashes a handful of nodes: 9 launches saved per tree).
+__global__ __launch_bounds__(256) void merkle_top_kernel(uint64_t *nodes, uint64_t level_begin, uint64_t level_end) {
+    while (level_begin != level_end) {
+        const uint64_t new_begin = level_begin / 2, count = level_begin - new_begin;
+        const uint64_t k = threadIdx.x;
+        if (k < count) {
+            const uint64_t *ch = nodes + (level_begin + 2 * k) * 4;
+            uint64_t st[25];
+#pragma unroll
+            for (int j = 0; j < 8; j++) st[j] = ch[j];
+            st[8] = 0x01ull;
+#pragma unroll
+            for (int j = 9; j < 25; j++) st[j] = 0;
+            st[16] = 0x8000000000000000ull;
+            keccak_f1600(st);
+            uint64_t *out = nodes + (new_begin + k) * 4;
+            out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+        }
+        __threadfence_block();
+        __syncthreads();
+        level_end = level_begin - 1;
+        level_begin = new_begin;
+    }
+}
+
 // d_nodes: (2 * 2^log2n - 1) * 32 bytes, root first
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
                          void *d_nodes, hipStream_t stream) {
@@ -141,6 +167,12 @@ int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64
     while (level_begin != level_end) {
         const uint64_t new_begin = level_begin / 2;
         const uint64_t count = level_begin - new_begin;
+        if (count <= 256) {   // the rest of the tree in one launch
+            pe = c.prof_begin(stream);
+            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, (uint64_t *)d_nodes, level_begin, level_end);
+            c.prof_end("merkle_top_kernel", pe, stream);
+            break;
+        }
         pe = c.prof_begin(stream);
         hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint64_t *)d_nodes,
                            level_begin, new_begin, count);
