@@ -142,7 +142,8 @@ int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const 
  * zero-padded to 2^log2n, i.e. Polynomial::evaluate_fft / evaluate_offset_fft with blowup_factor / domain_size
  * (math/src/fft/polynomial.rs:30-38) as the STARK prover calls it (provers/stark/src/prover.rs:150-167), without
  * materialising the padding: the log2n - log2_coeffs stages that would only replicate the block are skipped.
- * 256-bit fields only; d_out must not alias d_coeffs. */
+ * All fields and layouts (BASELINE config 4, the BabyBear STARK LDE, is this call with batch = 4); d_out must not alias
+ * d_coeffs. */
 int lw_hip_ntt_lde_device(lw_field_t field, lw_layout_t layout, const void *d_coeffs, uint32_t log2_coeffs, void *d_out,
                           uint32_t log2n, uint32_t batch, const void *coset_offset_or_null, void *hip_stream);
 
@@ -242,12 +243,31 @@ int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, co
                        size_t domain_size, void *out_poly, size_t *out_poly_len, void *out_evaluation, uint8_t *out_root,
                        uint8_t *out_nodes_or_null);
 
+/* The same layer with every large object resident in HBM (commit_phase's loop, provers/stark/src/fri/mod.rs:44-58, keeps
+ * current_poly and the layers; only the challenge and the 32-byte root go through the transcript): d_coeffs holds
+ * n_coeffs coefficients; d_out_poly receives p' as a zero-padded block of max(2, next_power_of_two(ceil(n_coeffs/2)))
+ * coefficients — the next layer's d_coeffs (pass ceil(n_coeffs/2) or the block length, trailing zeros change nothing);
+ * d_out_evaluation_or_null: domain_size elements, bit-reversed order; d_nodes_or_null: (domain_size - 1) x 32 bytes, root
+ * first; out_root_or_null: host, 32 bytes (synchronises the stream when given).  zeta and coset_offset are host
+ * pointers.  d_nodes_or_null == NULL: fold only — the last step of commit_phase (mod.rs:61-63), whose constant
+ * coefficient is the value sent to the verifier; domain_size and coset_offset are then ignored. */
+int lw_stark_fri_layer_device(lw_field_t field, const void *d_coeffs, size_t n_coeffs, const void *zeta, const void *coset_offset,
+                              size_t domain_size, void *d_out_poly, void *d_out_evaluation_or_null, void *d_nodes_or_null,
+                              uint8_t *out_root_or_null, void *hip_stream);
+
 /* ---- Groth16 quotient (SURVEY 8f "next" #3) ----
  * QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) once the variable
  * polynomials L, R, O have been accumulated: n_coeffs <= num_gates BLS12-381 FrElements each, num_gates a power of two.
  * Writes 2*num_gates coefficients of h (and the stripped length, as Polynomial::new would leave it). */
 int lw_groth16_h_coefficients(const void *l_coeffs, const void *r_coeffs, const void *o_coeffs, size_t n_coeffs, size_t num_gates,
                               void *out_h, size_t *coeff_len);
+
+/* Device-resident form: d_l / d_r / d_o hold n_coeffs FrElements each, d_out_h receives 2*num_gates coefficients (trailing
+ * zeros included) and stays in HBM for the MSM that consumes it — Prover::prove feeds h straight into
+ * msm(h.representative(), z_powers_of_tau_g1[..h.len()]) (provers/groth16/src/prover.rs:68-72,97-101), which is
+ * lw_hip_msm_srs_fr_device on d_out_h.  coeff_len_or_null (host): the stripped length; asking for it synchronises. */
+int lw_groth16_h_coefficients_device(const void *d_l, const void *d_r, const void *d_o, size_t n_coeffs, size_t num_gates, void *d_out_h,
+                                     size_t *coeff_len_or_null, void *hip_stream);
 
 /* ---- MSM ----
  * scalars: n x 4 u64, canonical integers, MS limb first (callers pass .representative()).
@@ -292,6 +312,8 @@ int lw_hip_msm_srs_device(const lw_srs_t *srs, const uint64_t *d_scalars, size_t
                           void *hip_stream);
 /* scalars as stored FrElements (Montgomery form), see lw_hip_msm_fr */
 int lw_hip_msm_srs_fr(const lw_srs_t *srs, const uint64_t *fr_elements, size_t n_scalars, void *out_point);
+int lw_hip_msm_srs_fr_device(const lw_srs_t *srs, const uint64_t *d_fr_elements, size_t n_scalars, void *out_point_host,
+                             void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ EXPORTS = [
     "lw_hip_msm_fr", "lw_hip_msm_fr_device", "lw_groth16_h_coefficients",
     "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
     "lw_hip_srs_create", "lw_hip_srs_create_device", "lw_hip_srs_destroy", "lw_hip_msm_srs", "lw_hip_msm_srs_device",
-    "lw_hip_msm_srs_fr",
+    "lw_hip_msm_srs_fr", "lw_hip_msm_srs_fr_device", "lw_stark_fri_layer_device", "lw_groth16_h_coefficients_device",
     "lw_hip_ec_add_outer_device",
     "lw_hip_comm_unique_id", "lw_hip_comm_init", "lw_hip_comm_shutdown", "lw_hip_comm_info",
     "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_msm_sharded_device",
@@ -126,6 +126,12 @@ def lib():
     L.lw_hip_msm_srs_fr.restype = i
     L.lw_hip_msm_srs_device.argtypes = [vp, vp, sz, vp, vp]
     L.lw_hip_msm_srs_device.restype = i
+    L.lw_hip_msm_srs_fr_device.argtypes = [vp, vp, sz, vp, vp]
+    L.lw_hip_msm_srs_fr_device.restype = i
+    L.lw_stark_fri_layer_device.argtypes = [i, vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
+    L.lw_stark_fri_layer_device.restype = i
+    L.lw_groth16_h_coefficients_device.argtypes = [vp, vp, vp, sz, sz, vp, C.POINTER(sz), vp]
+    L.lw_groth16_h_coefficients_device.restype = i
     L.lw_hip_ec_add_outer_device.argtypes = [i, vp, sz, vp, sz, vp, vp]
     L.lw_hip_ec_add_outer_device.restype = i
     L.lw_hip_comm_unique_id.argtypes = [vp]

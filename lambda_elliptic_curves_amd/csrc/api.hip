@@ -70,14 +70,19 @@ Context &ctx() {
     return c;
 }
 
+const char *tuning_env(const char *name) {
+    static const bool on = [] { const char *e = getenv("LW_HIP_TUNING"); return e && atoi(e) == 1; }();
+    return on ? getenv(name) : nullptr;
+}
+
 void ntt_set_max_pass_stages(uint32_t r);
 void ntt_set_debug(uint32_t d);
 
 static int init_locked(Context &c, const int *device_ids, int n_devices) {
 #ifdef LW_HIP_ABLATION
-    if (const char *e = getenv("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));   // wrong results, timing only
+    if (const char *e = tuning_env("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));   // wrong results, timing only
 #endif
-    if (const char *e = getenv("LW_HIP_NTT_MAX_R")) ntt_set_max_pass_stages((uint32_t)atoi(e));
+    if (const char *e = tuning_env("LW_HIP_NTT_MAX_R")) ntt_set_max_pass_stages((uint32_t)atoi(e));
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -152,6 +157,7 @@ void Context::release_all() {
     profiling = false;
     host_io_a.release();
     host_io_b.release();
+    pipe_tmp.release();
     timings.twiddle_bytes = timings.scratch_bytes = 0;
 }
 
@@ -191,7 +197,8 @@ int ensure_init() {
 int ntt256_device(Context &c, int field, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
                   uint64_t stride, const uint32_t *coset_words, hipStream_t stream, uint32_t in_log2);
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
-                  uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream);
+                  uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream, uint32_t in_log2);
+int broadcast_device(size_t elem_bytes, const void *d_in, void *d_out, uint64_t n, uint32_t batch, uint64_t out_stride, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points);
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
@@ -212,6 +219,7 @@ int fri_layer_device(Context &c, lw_field_t field, const void *d_coeffs, uint64_
                      hipStream_t stream);
 int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d_o, uint32_t log2_gates, void *d_out, void *d_tmp,
                      hipStream_t stream);
+int stripped_length_device(const void *d_elems, uint64_t n, uint64_t *d_len, hipStream_t stream);
 
 int ntt256_gen_powers(int field, uint32_t order, uint64_t count, uint32_t bitrev, bool inverse, const uint32_t *scale_words, void *d_out,
                       hipStream_t stream);
@@ -246,7 +254,7 @@ static void words_from_ref(const void *ref, uint32_t *w) {
     for (int k = 0; k < 8; k++) w[k] = m[2 * (3 - k / 2) + (k & 1)];
 }
 
-// in_log2 < log2n (256-bit fields, forward only): low-degree extension of 2^in_log2 coefficients, see ntt256.hip
+// in_log2 < log2n (forward only): low-degree extension of dense blocks of 2^in_log2 coefficients, see ntt256.hip / ntt_bb.hip
 int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                       uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream, uint32_t in_log2) {
     int rc = check_field_layout(field, layout);
@@ -277,8 +285,8 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
         return LW_ERR_BAD_ARG;
     }
     if (in_log2 > log2n) in_log2 = log2n;
-    if (in_log2 < log2n && (field == LW_FIELD_BABYBEAR || dir != LW_DIR_FORWARD || d_in == d_out)) {
-        set_error("low-degree extension needs a 256-bit field, the forward direction and distinct buffers");
+    if (in_log2 < log2n && (dir != LW_DIR_FORWARD || d_in == d_out)) {
+        set_error("low-degree extension needs the forward direction and distinct buffers");
         return LW_ERR_BAD_ARG;
     }
     // grid.y carries the batch: split very wide batches
@@ -295,7 +303,10 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
         }
         return LW_OK;
     }
-    if (field == LW_FIELD_BABYBEAR) return ntt_bb_device(c, layout, dir, d_in, d_out, log2n, batch, stride, coset, stream);
+    if (in_log2 == 0 && log2n > 0)   // a constant polynomial: every evaluation is c_0 (times offset^0), no stage left to run
+        return broadcast_device(lw_hip_field_elem_bytes(field, layout), d_in, d_out, 1ull << log2n, batch,
+                                stride ? stride : ((uint64_t)1 << log2n), stream);
+    if (field == LW_FIELD_BABYBEAR) return ntt_bb_device(c, layout, dir, d_in, d_out, log2n, batch, stride, coset, stream, in_log2);
     uint32_t cw[8];
     if (coset) words_from_ref(coset, cw);
     return ntt256_device(c, (int)field, dir, d_in, d_out, log2n, batch, stride, coset ? cw : nullptr, stream, in_log2);
@@ -645,13 +656,13 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
     if (en.rc) return en.rc;
     Context &c = en.c;
     auto t0 = std::chrono::steady_clock::now();
-    // Zero padding happens after scaling in the reference, so padded slots stay zero either way.  For the 256-bit
-    // fields only the power-of-two block that holds the coefficients is uploaded; the transform extends it (LDE path).
+    // Zero padding happens after scaling in the reference, so padded slots stay zero either way.  Only the power-of-two
+    // block that holds the coefficients is uploaded; the transform extends it (LDE path).
     size_t block = 1;
     while (block < clen) block <<= 1;
     uint32_t in_log2 = 0;
     while (((size_t)1 << in_log2) < block) in_log2++;
-    const bool lde = field != LW_FIELD_BABYBEAR && in_log2 >= 1 && in_log2 < log2n;
+    const bool lde = in_log2 >= 1 && in_log2 < log2n;
     const size_t up = lde ? block : len;
     if (c.host_io_a.ensure(up * eb) || c.host_io_b.ensure(len * eb)) return LW_ERR_ALLOC;
     Prefault pf;
@@ -773,10 +784,9 @@ int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, co
     uint32_t zw[8];
     words_from_ref(zeta, zw);
     LW_HIP_CHECK(hipMemcpy(da, coeffs, a_coeffs, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
-    LW_HIP_CHECK(hipMemcpy(da + a_coeffs, zw, 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     char *d_poly = da + a_coeffs + a_zeta;
     char *d_eval = db, *d_eval_br = db + domain_size * 32, *d_nodes = db + 2 * domain_size * 32;
-    rc = fri_layer_device(c, field, da, n_coeffs, (const uint32_t *)(da + a_coeffs), coset_offset, lgd, d_poly, lgb, d_eval, d_eval_br, d_nodes, 0);
+    rc = fri_layer_device(c, field, da, n_coeffs, zw, coset_offset, lgd, d_poly, lgb, d_eval, d_eval_br, d_nodes, 0);
     if (rc) return rc;
     LW_HIP_CHECK(hipMemcpy(out_poly, d_poly, n_out * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
     LW_HIP_CHECK(hipMemcpy(out_evaluation, d_eval_br, domain_size * 32, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
@@ -786,6 +796,87 @@ int lw_stark_fri_layer(lw_field_t field, const void *coeffs, size_t n_coeffs, co
         size_t clen = n_out;
         while (clen > 0 && elem_is_zero((const unsigned char *)out_poly + (clen - 1) * 32, 32)) clen--;
         *out_poly_len = clen;
+    }
+    return LW_OK;
+}
+
+// The same layer on device-resident buffers: only zeta (in) and the 32-byte root (out) cross the bus, which is all the
+// transcript between two layers of commit_phase needs (provers/stark/src/fri/mod.rs:44-58).
+int lw_stark_fri_layer_device(lw_field_t field, const void *d_coeffs, size_t n_coeffs, const void *zeta, const void *coset_offset,
+                              size_t domain_size, void *d_out_poly, void *d_out_evaluation_or_null, void *d_nodes_or_null,
+                              uint8_t *out_root_or_null, void *hip_stream) {
+    if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("FRI layer supports the 256-bit fields"); return LW_ERR_BAD_ARG; }
+    if (!d_coeffs || !zeta || !d_out_poly || n_coeffs == 0 || d_out_poly == d_coeffs) { set_error("null, empty or aliased argument"); return LW_ERR_BAD_ARG; }
+    const bool layer = d_nodes_or_null != nullptr;
+    if (!layer && (d_out_evaluation_or_null || out_root_or_null)) { set_error("an evaluation or a root needs d_nodes"); return LW_ERR_BAD_ARG; }
+    const size_t n_out = (n_coeffs + 1) / 2;
+    uint32_t lgd = 0, lgb = 1;
+    while (((size_t)1 << lgb) < n_out) lgb++;
+    if (layer) {
+        if (!coset_offset) { set_error("null coset offset"); return LW_ERR_BAD_ARG; }
+        if (domain_size < 2 || (domain_size & (domain_size - 1))) {
+            set_error("Input length is %zu, which is not a power of two", domain_size);
+            return LW_ERR_INPUT_NOT_POW2;
+        }
+        while (((size_t)1 << lgd) < domain_size) lgd++;
+        if (((size_t)1 << lgb) > domain_size) { set_error("folded polynomial of %zu coefficients exceeds the domain %zu", n_out, domain_size); return LW_ERR_BAD_ARG; }
+        if (lgd > field_two_adicity(field)) { set_error("no primitive 2^%u-th root of unity in this field", lgd); return LW_ERR_ROOT_OF_UNITY; }
+    }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    // natural-order evaluation (the tree and the bit-reversed copy are made from it): library scratch
+    if (layer && c.pipe_tmp.ensure(domain_size * 32)) return LW_ERR_ALLOC;
+    uint32_t zw[8];
+    words_from_ref(zeta, zw);
+    int rc = fri_layer_device(c, field, d_coeffs, n_coeffs, zw, coset_offset, lgd, d_out_poly, lgb, layer ? c.pipe_tmp.p : nullptr,
+                              d_out_evaluation_or_null, d_nodes_or_null, en.stream);
+    if (rc) return rc;
+    if (out_root_or_null) {
+        LW_HIP_CHECK(hipMemcpyAsync(out_root_or_null, d_nodes_or_null, 32, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
+    }
+    return LW_OK;
+}
+
+// calculate_h_coefficients on device-resident coefficient vectors; h stays in HBM for the MSM that consumes it
+// (provers/groth16/src/prover.rs:68-72,97-101 -> lw_hip_msm_srs_fr_device)
+int lw_groth16_h_coefficients_device(const void *d_l, const void *d_r, const void *d_o, size_t n_coeffs, size_t num_gates, void *d_out_h,
+                                     size_t *coeff_len_or_null, void *hip_stream) {
+    if (!d_out_h || (n_coeffs && (!d_l || !d_r || !d_o))) { set_error("null argument"); return LW_ERR_BAD_ARG; }
+    if (num_gates < 1 || (num_gates & (num_gates - 1))) {
+        set_error("Input length is %zu, which is not a power of two", num_gates);
+        return LW_ERR_INPUT_NOT_POW2;
+    }
+    if (n_coeffs > num_gates) { set_error("%zu coefficients for %zu gates", n_coeffs, num_gates); return LW_ERR_BAD_ARG; }
+    uint32_t lg = 0;
+    while (((size_t)1 << lg) < num_gates) lg++;
+    if (lg + 1 > Fr381::TWO_ADICITY) { set_error("no primitive 2^%u-th root of unity in this field", lg + 1); return LW_ERR_ROOT_OF_UNITY; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    const size_t n = 2 * num_gates, blk = num_gates < 2 ? 2 : num_gates;
+    const bool staged = n_coeffs != blk;   // shorter vectors are zero padded into library scratch first
+    if (c.pipe_tmp.ensure((3 * n + (staged ? 3 * blk : 0)) * 32 + 256)) return LW_ERR_ALLOC;
+    char *ev = (char *)c.pipe_tmp.p, *st = ev + 3 * n * 32;
+    const void *src[3] = {d_l, d_r, d_o};
+    if (staged) {
+        LW_HIP_CHECK(hipMemsetAsync(st, 0, 3 * blk * 32, en.stream), LW_ERR_LAUNCH);
+        for (int k = 0; k < 3; k++) {
+            if (n_coeffs) LW_HIP_CHECK(hipMemcpyAsync(st + (size_t)k * blk * 32, src[k], n_coeffs * 32, hipMemcpyDeviceToDevice, en.stream), LW_ERR_LAUNCH);
+            src[k] = st + (size_t)k * blk * 32;
+        }
+    }
+    int rc = groth16_h_device(c, src[0], src[1], src[2], lg, d_out_h, ev, en.stream);
+    if (rc) return rc;
+    if (coeff_len_or_null) {   // Polynomial::new's stripped length, for callers that slice the SRS by it (prover.rs:98-100)
+        uint64_t *d_len = (uint64_t *)(ev + 3 * n * 32 + (staged ? 3 * blk * 32 : 0));
+        rc = stripped_length_device(d_out_h, n, d_len, en.stream);
+        if (rc) return rc;
+        uint64_t len = 0;
+        LW_HIP_CHECK(hipMemcpyAsync(&len, d_len, 8, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
+        *coeff_len_or_null = (size_t)len;
     }
     return LW_OK;
 }
@@ -900,9 +991,9 @@ static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream
     // of 2^19 buckets (msm_core.cuh build_fold): 13 x the memory of the affine rows — 27 GiB for 2^24 BLS12-381 G1 points,
     // which is what 288 GB of HBM are for — taken only while it stays below a quarter of the free memory.
     // LW_HIP_SRS_FOLD=0 keeps the single copy.
-    static const bool fold_env = [] { const char *e = getenv("LW_HIP_SRS_FOLD"); return !e || atoi(e) != 0; }();
+    static const bool fold_env = [] { const char *e = tuning_env("LW_HIP_SRS_FOLD"); return !e || atoi(e) != 0; }();
     const uint32_t fold_c = 20, fold_w = (256 + fold_c) / fold_c;
-    const char *fm = getenv("LW_HIP_SRS_FOLD_MIN");   // log2 of the smallest folded set (tests; read per call)
+    const char *fm = tuning_env("LW_HIP_SRS_FOLD_MIN");   // log2 of the smallest folded set (tests; read per call)
     const int fold_min = fm ? atoi(fm) : 19;
     bool fold = fold_env && n >= ((size_t)1 << (fold_min < 0 ? 0 : fold_min > 40 ? 40 : fold_min)) && (((uint64_t)n * fold_w) >> 31) == 0;
     if (fold) {
@@ -988,6 +1079,9 @@ int lw_hip_msm_srs_fr(const lw_srs_t *srs, const uint64_t *fr_elements, size_t n
 }
 int lw_hip_msm_srs_device(const lw_srs_t *srs, const uint64_t *d_scalars, size_t n_scalars, void *out_point_host, void *hip_stream) {
     return msm_srs_entry(srs, d_scalars, n_scalars, out_point_host, (hipStream_t)hip_stream, 0, 0);
+}
+int lw_hip_msm_srs_fr_device(const lw_srs_t *srs, const uint64_t *d_fr_elements, size_t n_scalars, void *out_point_host, void *hip_stream) {
+    return msm_srs_entry(srs, d_fr_elements, n_scalars, out_point_host, (hipStream_t)hip_stream, 0, 1);
 }
 
 }  // extern "C"

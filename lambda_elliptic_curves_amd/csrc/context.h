@@ -21,6 +21,9 @@
 namespace lw {
 
 void set_error(const char *fmt, ...);
+// Diagnostic / A-B switches (LW_HIP_MSM_C, LW_HIP_NTT_PLAN, ...) are honoured only in processes started with
+// LW_HIP_TUNING=1 (read once): a stray variable in a prover's environment cannot change the schedule.
+const char *tuning_env(const char *name);
 extern thread_local std::string g_last_error;
 
 #define LW_HIP_CHECK(expr, code)                                                            \
@@ -88,6 +91,7 @@ struct Context {
     hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
+    DeviceBuf pipe_tmp;               // intermediates of the device-resident pipelines (FRI layer evaluation, Groth16 cosets)
     lw_timings_t timings = {};
     // Cross-stream ordering of the context-owned buffers (scratch, tables, staging, MSM workspace): every entry point
     // records `order_event` on its launch stream when it returns; a call arriving on a different stream first makes

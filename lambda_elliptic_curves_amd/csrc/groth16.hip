@@ -74,4 +74,20 @@ int groth16_h_device(Context &c, const void *d_l, const void *d_r, const void *d
     return ntt_device_locked(c, LW_FIELD_BLS12_381_FR, LW_LAYOUT_U64_LIMBS_MS_FIRST, LW_DIR_INVERSE, ev, d_out, L, 1, 0, off_ref, stream, L);
 }
 
+// Polynomial::new strips trailing zero coefficients (math/src/polynomial/mod.rs:19-31): *d_len = 1 + index of the last
+// non-zero 32-byte element, 0 for the zero polynomial
+__global__ void stripped_length_kernel(const uint4 *e, uint64_t n, unsigned long long *len) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 a = e[2 * i], b = e[2 * i + 1];
+    if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicMax(len, (unsigned long long)(i + 1));
+}
+int stripped_length_device(const void *d_elems, uint64_t n, uint64_t *d_len, hipStream_t stream) {
+    LW_HIP_CHECK(hipMemsetAsync(d_len, 0, 8, stream), LW_ERR_LAUNCH);
+    if (n) hipLaunchKernelGGL(stripped_length_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, (const uint4 *)d_elems, n,
+                              (unsigned long long *)d_len);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
 }  // namespace lw

@@ -596,12 +596,12 @@ size_t msm_order_tmp_bytes() { return 8 * ORDER_BINS; }
 // 32); when the items do not fill the machine a work-item's chain IS the kernel time, so short pieces and one more
 // round win (2^14, c = 8: 1.60 ms at 16, 2.07 at 64).  LW_HIP_MSM_CH: tuning only.
 uint32_t msm_ch(uint64_t items) {
-    static const int env = [] { const char *e = getenv("LW_HIP_MSM_CH"); return e ? atoi(e) : 0; }();
+    static const int env = [] { const char *e = tuning_env("LW_HIP_MSM_CH"); return e ? atoi(e) : 0; }();
     if (env) return (uint32_t)(env < 4 ? 4 : (env > 128 ? 128 : env));
     return items < (1ull << 22) ? 16u : items < (1ull << 27) ? 32u : 64u;
 }
 int msm_piece_order_enabled() {
-    static int v = [] { const char *e = getenv("LW_HIP_MSM_ORDER"); return e ? atoi(e) : 1; }();
+    static int v = [] { const char *e = tuning_env("LW_HIP_MSM_ORDER"); return e ? atoi(e) : 1; }();
     return v;
 }
 
@@ -673,11 +673,11 @@ void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, ui
 size_t msm_scan_scratch_bytes(uint32_t K) { return 8 * (size_t)((K + SCAN_TILE - 1) / SCAN_TILE) + 256; }
 
 uint32_t msm_g_log() {
-    static uint32_t g = [] { const char *e = getenv("LW_HIP_MSM_GLOG"); int v = e ? atoi(e) : 3; return (uint32_t)(v < 1 ? 1 : (v > 6 ? 6 : v)); }();
+    static uint32_t g = [] { const char *e = tuning_env("LW_HIP_MSM_GLOG"); int v = e ? atoi(e) : 3; return (uint32_t)(v < 1 ? 1 : (v > 6 ? 6 : v)); }();
     return g;
 }
 int msm_waves_per_simd() {
-    static int w = [] { const char *e = getenv("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
+    static int w = [] { const char *e = tuning_env("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
     return w;
 }
 
@@ -764,9 +764,9 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     // the mixed addition, one-line gathers and — BLS12-381 G1, BN254 G2 — the cheaper isomorphic curve (~10 ms less at
     // 2^24); below the per-group threshold (msm_normalize_min_log2) the conversion costs more than it saves.
     // LW_HIP_MSM_NORMALIZE=0 keeps the projective path.
-    static const bool auto_norm = [] { const char *e = getenv("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
+    static const bool auto_norm = [] { const char *e = tuning_env("LW_HIP_MSM_NORMALIZE"); return !e || atoi(e) != 0; }();
     hipEvent_t join = nullptr;
-    static const int norm_min_env = [] { const char *e = getenv("LW_HIP_MSM_NORM_MIN"); return e ? atoi(e) : -1; }();   // tuning only
+    static const int norm_min_env = [] { const char *e = tuning_env("LW_HIP_MSM_NORM_MIN"); return e ? atoi(e) : -1; }();   // tuning only
     const int norm_min_log2 = norm_min_env >= 0 ? norm_min_env : msm_normalize_min_log2(curve);
     if (!affine_points && auto_norm && n >= ((size_t)1 << norm_min_log2)) {
         const size_t aff_bytes = msm_affine_bytes(curve, n);
@@ -774,7 +774,7 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         // The normalisation reads only the points and the bucket sort only the scalars, so the normalisation runs on a
         // side stream beside the sort and the main stream joins it just before the first accumulation launch (both are
         // memory-bound: side by side they take about the sum of their standalone times less 0.5 ms, LW_HIP_MSM_SIDE).
-        static const bool side = [] { const char *e = getenv("LW_HIP_MSM_SIDE"); return !e || atoi(e) != 0; }();   // A/B only
+        static const bool side = [] { const char *e = tuning_env("LW_HIP_MSM_SIDE"); return !e || atoi(e) != 0; }();   // A/B only
         if (!side) {
             int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
             if (rc) return rc;

@@ -273,7 +273,17 @@ struct Carver {   // bump allocator over the context workspace
         used += bytes;
         return p;
     }
+    // true once a real (non-dry) carve-out has run past the workspace the dry run sized: checked before every launch
+    // that would touch the new pointers
+    bool overrun() const { return base && used > cap; }
 };
+#define LW_MSM_WS_CHECK(cv)                                                                                          \
+    do {                                                                                                             \
+        if ((cv).overrun()) {                                                                                        \
+            set_error("internal: MSM workspace of %zu bytes is too small (%zu needed so far)", (cv).cap, (cv).used); \
+            return LW_ERR_ALLOC;                                                                                     \
+        }                                                                                                            \
+    } while (0)
 
 // Window width c (signed digits, W = ceil(257 / c) windows of 2^(c-1) buckets): the bucket additions N * W fall with c, the
 // running sums over W * 2^(c-1) buckets (about three additions per bucket, latency-bound levels) grow with it.  Only widths
@@ -283,7 +293,7 @@ struct Carver {   // bump allocator over the context workspace
 // 18.9, c = 18 18.3, c = 19 17.1, c = 20 16.5).  Measured with LW_HIP_MSM_C (tools/ab_msm_csweep.sh): 2^14 c = 8 1.60 ms
 // against 1.92 at c = 16; 2^16 2.02 (c = 16) against 2.10; 2^23 c = 20 27.3 against 28.6; 2^24 c = 20 49.1 against 54.8.
 static uint32_t pick_window(size_t n) {
-    const char *e = getenv("LW_HIP_MSM_C");   // tuning and tests only; read per call so a test can sweep it
+    const char *e = tuning_env("LW_HIP_MSM_C");   // tuning and tests only; read per call so a test can sweep it
     const int c_env = e ? atoi(e) : 0;
     if (c_env >= 3 && c_env <= (int)msm_max_window_bits()) return (uint32_t)c_env;
     if (n < ((size_t)1 << 15)) return 8u;
@@ -308,8 +318,8 @@ struct MsmRunner {
         hipEvent_t pe = c.prof_begin(stream);
         // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
         // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
-        static const uint32_t chk_env = [] { const char *e = getenv("LW_HIP_MSM_CHK"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning only
-        const uint32_t chk = chk_env ? chk_env : (n >= ((size_t)1 << 22) ? 128 : 32);
+        static const uint32_t chk_env = [] { const char *e = tuning_env("LW_HIP_MSM_CHK"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning only
+        const uint32_t chk = chk_env ? std::min(std::max(chk_env, 1u), 1024u) : (n >= ((size_t)1 << 22) ? 128 : 32);
         const uint64_t items = (n + chk - 1) / chk;
         hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                            stream, d_in, (uint64_t)n, chk, d_out, c.msm_prefix.p);
@@ -355,6 +365,7 @@ struct MsmRunner {
         const uint32_t g = 1u << MSM_G_LOG;
         if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
             char *out = (char *)cv.take(PB * 2 * (size_t)nwin);
+            LW_MSM_WS_CHECK(cv);
             if (cv.base) {
                 hipEvent_t pe = c.prof_begin(stream);
                 hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((2 * nwin + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
@@ -367,6 +378,7 @@ struct MsmRunner {
         }
         const uint32_t ng = (n + g - 1) / g;
         char *lvl = (char *)cv.take(PB * 2 * (size_t)nwin * ng);
+        LW_MSM_WS_CHECK(cv);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
             hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((uint32_t)((2 * (uint64_t)ng * nwin + MSM_THREADS - 1) / MSM_THREADS)),
@@ -377,6 +389,7 @@ struct MsmRunner {
         int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2);
         if (rc) return rc;
         char *S = (char *)cv.take(PB * nwin), *A = (char *)cv.take(PB * nwin);
+        LW_MSM_WS_CHECK(cv);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
             hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2, MSM_G_LOG, nwin, (void *)S, (void *)A);
@@ -407,6 +420,7 @@ struct MsmRunner {
         uint64_t *items = (uint64_t *)cv.take(8 * n * W);
         uint32_t *dig = (uint32_t *)cv.take(4 * (size_t)W * msm_sort_padded_points(n));
         uint32_t maxlen = maxlen_hint;
+        LW_MSM_WS_CHECK(cv);
         if (!dry) {
             // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
             LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
@@ -427,6 +441,7 @@ struct MsmRunner {
         uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
         bool first = true;                 // (the dry run has no pointers to tell the rounds apart)
         char *buckets = (char *)cv.take(PB * (size_t)K);
+        LW_MSM_WS_CHECK(cv);
         auto launch = [&](const uint32_t *out_off, const uint32_t *perm_t, const uint32_t *perm_key, uint32_t total, void *pout,
                           const char *name) {
             const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
@@ -449,6 +464,7 @@ struct MsmRunner {
             const bool ord = ordered && first;
             uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * out_bound) : nullptr;
             uint32_t *perm_key = ord ? (uint32_t *)cv.take(4 * out_bound) : nullptr;
+            LW_MSM_WS_CHECK(cv);
             if (!dry) {
                 msm_launch_scan(seg, out_off, K, (int)CH, maxlen_d, scan_tmp, stream);
                 uint32_t total = 0;
@@ -471,6 +487,7 @@ struct MsmRunner {
         {
             const bool ord = ordered && first;
             uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * (size_t)K) : nullptr;
+            LW_MSM_WS_CHECK(cv);
             if (!dry) {
                 if (ord) msm_launch_piece_order(c, seg, nullptr, K, K, order_tmp, perm_t, nullptr, stream);
                 launch(nullptr, perm_t, nullptr, K, nullptr, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
@@ -500,10 +517,13 @@ struct MsmRunner {
                 set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
                 return LW_ERR_BAD_ARG;
             }
-            // size the workspace for the worst case (one bucket holding every point)
+            // size the workspace for the worst case: one bucket holding every item.  A folded SRS sorts the items of all W
+            // windows into one bucket set, so its longest bucket can hold n * W items (every scalar with the same digit in
+            // every window), which takes more rounds of partial sums than n items do.
             Carver dry{nullptr, 0};
             char *S_d = nullptr, *A_d = nullptr;
-            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, &A_d, (uint32_t)std::min<size_t>(n, 0xffffffffu));
+            const uint64_t worst_len = fold_stride ? (uint64_t)n * W : (uint64_t)n;
+            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, &A_d, (uint32_t)std::min<uint64_t>(worst_len, 0xffffffffu));
             if (rc) return rc;
             if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
             Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};

@@ -115,7 +115,7 @@ static NttPlan plan_passes(uint32_t L, uint32_t max_r, uint32_t skip = 0) {
             }
     }
     // tuning only: LW_HIP_NTT_PLAN="8,8,6" fixes the stages per pass for transforms whose stage count matches the sum
-    static const char *plan_env = getenv("LW_HIP_NTT_PLAN");
+    static const char *plan_env = tuning_env("LW_HIP_NTT_PLAN");
     if (plan_env) {
         uint32_t v[8], cnt = 0, sum = 0;
         for (const char *q = plan_env; *q && cnt < 8;) {
@@ -156,8 +156,8 @@ static void split_steps(uint32_t r, NttPassParams &p) {
     }
 }
 
-static bool g_ntt_wave_local_all = [] { const char *e = getenv("LW_HIP_NTT_WAVE_LOCAL"); return e && atoi(e) == 2; }();   // A/B: also in non-last passes
-static bool g_ntt_wave_local = [] { const char *e = getenv("LW_HIP_NTT_WAVE_LOCAL"); return !e || atoi(e) != 0; }();   // A/B switch
+static bool g_ntt_wave_local_all = [] { const char *e = tuning_env("LW_HIP_NTT_WAVE_LOCAL"); return e && atoi(e) == 2; }();   // A/B: also in non-last passes
+static bool g_ntt_wave_local = [] { const char *e = tuning_env("LW_HIP_NTT_WAVE_LOCAL"); return !e || atoi(e) != 0; }();   // A/B switch
 static uint32_t g_ntt_max_r = 8;
 void ntt_set_max_pass_stages(uint32_t r) { g_ntt_max_r = r < 1 ? 1 : (r > 8 ? 8 : r); }
 
@@ -194,7 +194,7 @@ static void launch_pass(bool last, dim3 grid, hipStream_t stream, const NttPassP
     // full-size tiles (every pass of a 2^24 transform, the last pass from 2^16 on, the 6-stage passes of 2^20 and 2^26):
     // kernels with the tile shape compiled in
     constexpr bool FXOK = CFG::TILE == 2048 && CFG::THREADS == 512;
-    static const bool fx_env = [] { const char *e = getenv("LW_HIP_NTT_FX"); return !e || atoi(e) != 0; }();   // A/B only
+    static const bool fx_env = [] { const char *e = tuning_env("LW_HIP_NTT_FX"); return !e || atoi(e) != 0; }();   // A/B only
     int fx = 0;
     if (FXOK && fx_env && p.r == 8 && p.logC == 3 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 2) fx = 8;
     if (FXOK && fx_env && p.r == 7 && p.logC == 4 && p.nsteps == 4 && p.k[0] == 2 && p.k[1] == 2 && p.k[2] == 2 && p.k[3] == 1) fx = 7;   // (7,7,8)

@@ -36,7 +36,7 @@ template <int WORDS>
 __global__ void bitrev_gather_kernel(const uint32_t *in, uint32_t *out, uint32_t bits, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t j = bits <= 32 ? bitrev_bits((uint32_t)i, bits) : 0;
+    const uint64_t j = bitrev_bits((uint32_t)i, bits);   // bits <= 32: checked by bitrev_device
     if (WORDS == 8) {
         const uint4 *s = reinterpret_cast<const uint4 *>(in) + 2 * j;
         uint4 *d = reinterpret_cast<uint4 *>(out) + 2 * i;
@@ -76,7 +76,34 @@ int gen_twiddles_device(Context &c, lw_field_t field, lw_layout_t layout, uint32
     return LW_OK;
 }
 
+// out[b * out_stride + i] = in[b] for i < n: the low-degree extension of a constant polynomial (every evaluation is c_0,
+// on any coset: c_0 * h^0), elements of WORDS x 4 bytes
+template <int WORDS>
+__global__ void broadcast_kernel(const uint32_t *in, uint32_t *out, uint64_t n, uint64_t out_stride) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *s = in + (size_t)blockIdx.y * WORDS;
+    uint32_t *d = out + ((size_t)blockIdx.y * out_stride + i) * WORDS;
+#pragma unroll
+    for (int k = 0; k < WORDS; k++) d[k] = s[k];
+}
+int broadcast_device(size_t elem_bytes, const void *d_in, void *d_out, uint64_t n, uint32_t batch, uint64_t out_stride, hipStream_t stream) {
+    dim3 grid((uint32_t)((n + 255) / 256), batch);
+    if (elem_bytes == 32)
+        hipLaunchKernelGGL((broadcast_kernel<8>), grid, dim3(256), 0, stream, (const uint32_t *)d_in, (uint32_t *)d_out, n, out_stride);
+    else if (elem_bytes == 8)
+        hipLaunchKernelGGL((broadcast_kernel<2>), grid, dim3(256), 0, stream, (const uint32_t *)d_in, (uint32_t *)d_out, n, out_stride);
+    else
+        hipLaunchKernelGGL((broadcast_kernel<1>), grid, dim3(256), 0, stream, (const uint32_t *)d_in, (uint32_t *)d_out, n, out_stride);
+    LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+
 int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream) {
+    if (log2n > 32) {   // the index reversal is 32 bits wide (FFTError::OrderError territory: 2^33 elements are >= 32 GiB)
+        set_error("bit-reverse permutation of 2^%u elements: at most 2^32 are supported", log2n);
+        return LW_ERR_ORDER_TOO_LARGE;
+    }
     const uint64_t n = 1ull << log2n;
     dim3 grid((uint32_t)((n + 255) / 256));
     if (elem_bytes == 32)

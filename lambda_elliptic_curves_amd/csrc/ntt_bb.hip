@@ -38,6 +38,10 @@ struct BbPassParams {
     // = h^i while the first pass loads it (cos_in), or by h^-i * N^-1 while the last pass stores it (cos_out, N^-1 folded into hi)
     const uint32_t *cos_lo, *cos_hi;
     uint32_t cos_hbits, cos_in, cos_out;
+    // low-degree extension (first pass only): word g of the zero-padded input is read from in[g & in_mask] — after the
+    // log2(blow-up) stages that only pair data with padding the vector is the coefficient block replicated, so those
+    // stages are skipped (s0 starts there) and the padding is never materialised.  Plain transforms: all ones.
+    uint32_t in_mask;
     uint32_t dbg;              // ablation builds only (-DLW_HIP_ABLATION): bit0 skip butterflies, bit1 skip loads, bit2 skip stores, bit3 old last-pass mapping
 };
 
@@ -100,7 +104,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
             uint32_t g;
             if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
             else g = base + (m << lgS) + c;
-            x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<IN64>(gin, g);
+            x[j] = (LW_DBG(p) & 2) ? g : bb_load_word<IN64>(gin, g & p.in_mask);
         }
         if (p.cos_in) {   // c_i * h^i, fused into the first pass's load (its own loop: the loads above stay back to back)
 #pragma unroll
@@ -109,7 +113,7 @@ __device__ __forceinline__ void bb_item(const BbPassParams &p, uint32_t *lds, co
                 uint32_t g;
                 if (LAST) g = ((((hi_c << r) | m)) << lgV) | (c & ((1u << lgV) - 1));
                 else g = base + (m << lgS) + c;
-                x[j] = bb_mul(x[j], bb_coset_factor(p, g >> lgV));
+                x[j] = bb_mul(x[j], bb_coset_factor(p, (g & p.in_mask) >> lgV));
             }
         }
     } else {
@@ -348,10 +352,13 @@ static int bb_ensure_twiddles(Context &c, lw_dir_t dir, uint32_t log2n, hipStrea
     return LW_OK;
 }
 
+// in_log2 < log2n: low-degree extension of dense blocks of 2^in_log2 coefficients (forward, d_in != d_out)
 template <bool W64>
 static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
-                  uint64_t stride_elems, const void *coset, hipStream_t stream) {
+                  uint64_t stride_elems, const void *coset, hipStream_t stream, uint32_t in_log2) {
     const uint64_t n = 1ull << log2n;
+    const bool lde = in_log2 < log2n;
+    const uint32_t skip = lde ? log2n - in_log2 : 0;   // leading stages that only replicate the block
     const uint64_t nwords = n << lgV;
     const uint64_t wbytes = W64 ? 8 : 4;
     uint64_t stride = (stride_elems ? stride_elems : n) << lgV;   // in words
@@ -372,13 +379,16 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
 
     // pass plan: r <= 8 stages per pass; logC columns x components fill the tile
     const uint32_t max_r = 8;
-    int npass = (int)((log2n + max_r - 1) / max_r);
+    const uint32_t nstages = log2n - skip;
+    int npass = (int)((nstages + max_r - 1) / max_r);
     if (npass < 1) npass = 1;
     const bool need_scratch = npass > 1 || d_in == d_out;
     if (need_scratch && c.scratch.ensure((size_t)nwords * batch * wbytes)) return LW_ERR_ALLOC;
     // coset factors: h^i fused into the first pass's load (forward), h^-i * N^-1 into the last pass's store (inverse) —
     // a separate kernel with one exponentiation per element cost more than the transform (0.59 ms against 0.48 at 4 x 2^24)
-    const uint32_t cos_hbits = log2n < 12 ? log2n : 12, cos_nhi = 1u << (log2n - cos_hbits);
+    // (a low-degree extension scales the 2^in_log2 coefficients only: zero padding happens after Polynomial::scale)
+    const uint32_t cos_len = lde ? in_log2 : log2n;
+    const uint32_t cos_hbits = cos_len < 12 ? cos_len : 12, cos_nhi = 1u << (cos_len - cos_hbits);
     uint32_t *cos_lo = nullptr, *cos_hi = nullptr;
     if (coset) {
         if (c.bb_coset.ensure(4 * ((size_t)(1u << cos_hbits) + cos_nhi))) return LW_ERR_ALLOC;
@@ -394,7 +404,7 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
     }
 
     const void *src = d_in;
-    uint64_t src_stride = stride;
+    uint64_t src_stride = lde ? ((uint64_t)1 << (in_log2 + lgV)) : stride;
     bool src64 = W64;   // word type of `src`: the layout's in the caller's buffers, u32 in every intermediate this function writes
     if (npass == 1 && src == d_out) {
         LW_HIP_CHECK(hipMemcpy2DAsync(c.scratch.p, nwords * wbytes, d_in, stride * wbytes, nwords * wbytes, batch,
@@ -402,7 +412,7 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         src = c.scratch.p;
         src_stride = nwords;
     }
-    uint32_t base = log2n / npass, extra = log2n % npass, s = 0;
+    uint32_t base = nstages / npass, extra = nstages % npass, s = skip;
     for (int i = 0; i < npass; i++) {
         const bool last = (i == npass - 1);
         BbPassParams p{};
@@ -431,6 +441,7 @@ static int bb_run(Context &c, lw_dir_t dir, uint32_t lgV, const void *d_in, void
         p.cos_lo = cos_lo;
         p.cos_hi = cos_hi;
         p.cos_hbits = cos_hbits;
+        p.in_mask = (lde && i == 0) ? (uint32_t)(((uint64_t)1 << (in_log2 + lgV)) - 1) : 0xffffffffu;
         p.cos_in = (coset && dir == LW_DIR_FORWARD && i == 0) ? 1u : 0u;
         p.cos_out = (coset && dir == LW_DIR_INVERSE && last) ? 1u : 0u;
         if (last) {
@@ -513,11 +524,12 @@ const uint32_t *ntt_bb_twiddle_table(Context &c, lw_dir_t dir, uint32_t log2n, h
 uint32_t ntt_bb_root(uint32_t order, bool inverse) { return bb_host_root(order, inverse); }
 
 int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n, uint32_t batch,
-                  uint64_t stride, const void *coset_offset, hipStream_t stream) {
+                  uint64_t stride, const void *coset_offset, hipStream_t stream, uint32_t in_log2) {
+    if (in_log2 > log2n || in_log2 == 0) in_log2 = log2n;   // (in_log2 == 0 < log2n never arrives: ntt_device_locked broadcasts a constant)
     switch (layout) {
-        case LW_LAYOUT_BABYBEAR_U32_R32: return bb_run<false>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream);
-        case LW_LAYOUT_BABYBEAR_U64_R64: return bb_run<true>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream);
-        case LW_LAYOUT_EXT4_INTERLEAVED: return bb_run<true>(c, dir, 2, d_in, d_out, log2n, batch, stride, coset_offset, stream);
+        case LW_LAYOUT_BABYBEAR_U32_R32: return bb_run<false>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream, in_log2);
+        case LW_LAYOUT_BABYBEAR_U64_R64: return bb_run<true>(c, dir, 0, d_in, d_out, log2n, batch, stride, coset_offset, stream, in_log2);
+        case LW_LAYOUT_EXT4_INTERLEAVED: return bb_run<true>(c, dir, 2, d_in, d_out, log2n, batch, stride, coset_offset, stream, in_log2);
         default: set_error("bad BabyBear layout %d", (int)layout); return LW_ERR_BAD_ARG;
     }
 }

@@ -54,3 +54,57 @@ def fri_layer(field, coeffs, zeta, coset_offset, domain_size, return_nodes=False
                                      vp(root), vp(nodes)))
     out = (poly[:plen.value], ev, root.tobytes())
     return out + (nodes,) if return_nodes else out
+
+
+def fri_layer_device(field, t_coeffs, n_coeffs, zeta, coset_offset, domain_size, want_evaluation=True, stream=None):
+    """One layer of commit_phase with everything large resident in HBM: returns (t_poly, n_out, t_evaluation, t_nodes, root);
+    t_poly is the zero-padded block holding p' = 2*fold(p, zeta) (the next layer's input), n_out = ceil(n_coeffs/2)."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    z = np.ascontiguousarray(zeta, dtype=np.uint64).reshape(4)
+    off = np.ascontiguousarray(coset_offset, dtype=np.uint64).reshape(4)
+    n_out = (n_coeffs + 1) // 2
+    blk = max(2, 1 << (n_out - 1).bit_length())
+    t_poly = torch.empty((blk, 4), dtype=torch.int64, device=t_coeffs.device)
+    t_ev = torch.empty((domain_size, 4), dtype=torch.int64, device=t_coeffs.device) if want_evaluation else None
+    t_nodes = torch.empty(((domain_size - 1) * 4,), dtype=torch.int64, device=t_coeffs.device)
+    root = np.zeros(32, np.uint8)
+    check(L.lib().lw_stark_fri_layer_device(field.field, C.c_void_p(t_coeffs.data_ptr()), n_coeffs, z.ctypes.data_as(C.c_void_p),
+                                            off.ctypes.data_as(C.c_void_p), domain_size, C.c_void_p(t_poly.data_ptr()),
+                                            C.c_void_p(t_ev.data_ptr()) if want_evaluation else None, C.c_void_p(t_nodes.data_ptr()),
+                                            root.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+    return t_poly, n_out, t_ev, t_nodes, root.tobytes()
+
+
+def fri_fold_device(field, t_coeffs, n_coeffs, zeta, stream=None):
+    """2 * fold_polynomial(p, zeta) alone (the last step of commit_phase, fri/mod.rs:61-63): returns (t_poly, n_out)."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    z = np.ascontiguousarray(zeta, dtype=np.uint64).reshape(4)
+    n_out = (n_coeffs + 1) // 2
+    blk = max(2, 1 << (n_out - 1).bit_length())
+    t_poly = torch.empty((blk, 4), dtype=torch.int64, device=t_coeffs.device)
+    check(L.lib().lw_stark_fri_layer_device(field.field, C.c_void_p(t_coeffs.data_ptr()), n_coeffs, z.ctypes.data_as(C.c_void_p),
+                                            None, 0, C.c_void_p(t_poly.data_ptr()), None, None, None, C.c_void_p(stream)))
+    return t_poly, n_out
+
+
+def fri_commit_phase_device(field, number_layers, t_p0, n_coeffs, sample_zeta, append_root, coset_offset_sq, domain_size,
+                            want_evaluations=True):
+    """commit_phase (provers/stark/src/fri/mod.rs:22-75) with the polynomial, every layer's evaluation and tree in HBM.
+    The transcript stays with the caller: sample_zeta() -> FieldElement (4 x u64), append_root(bytes);
+    coset_offset_sq(k) -> the k-times squared coset offset as a FieldElement (the caller owns field arithmetic on scalars).
+    Returns (t_last_poly, layers) with layers = [(t_evaluation, t_nodes, root, domain_size)]."""
+    t_poly, n = t_p0, n_coeffs
+    layers = []
+    for k in range(1, number_layers):
+        zeta = sample_zeta()
+        domain_size //= 2
+        t_poly, n, t_ev, t_nodes, root = fri_layer_device(field, t_poly, n, zeta, coset_offset_sq(k), domain_size,
+                                                          want_evaluation=want_evaluations)
+        layers.append((t_ev, t_nodes, root, domain_size))
+        append_root(root)
+    t_last, _ = fri_fold_device(field, t_poly, n, sample_zeta())
+    return t_last, layers

@@ -108,6 +108,17 @@ class Srs:
                                             C.c_void_p(stream)))
         return out
 
+    def msm_fr_device(self, t_fr_elements, n, stream=None):
+        """Scalars as stored FrElements (Montgomery form) already on the device — e.g. the h coefficients
+        groth16.calculate_h_coefficients_device leaves in HBM (provers/groth16/src/prover.rs:68-72,97-101)."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        out = np.zeros(self.curve.point_words, dtype=np.uint64)
+        check(L.lib().lw_hip_msm_srs_fr_device(self._h, C.c_void_p(t_fr_elements.data_ptr()), n, out.ctypes.data_as(C.c_void_p),
+                                               C.c_void_p(stream)))
+        return out
+
     def close(self):
         if self._h:
             L.lib().lw_hip_srs_destroy(self._h)

@@ -768,3 +768,137 @@ int orc_merkle_commit_columns(const u64 *columns, uint32_t n_cols, uint32_t log2
     }
     return 0;
 }
+
+/* Leaves and every tree level are independent hashes; the checker at the sizes the GPU path is timed on (2^22-2^24
+   leaves) splits exactly the loops of orc_merkle_commit_columns over `threads` workers.  Same nodes, same order. */
+typedef struct { const u64 *columns; uint32_t n_cols; size_t n; int bit_reverse; uint8_t *nodes; size_t level_begin, new_begin, lo, hi; int leaves; } mk_job;
+static void *mk_worker(void *arg) {
+    mk_job *j = (mk_job *)arg;
+    if (j->leaves) {
+        uint8_t *row = (uint8_t *)malloc((size_t)j->n_cols * 32 + 1);
+        uint8_t *leaves = j->nodes + (j->n - 1) * 32;
+        for (size_t i = j->lo; i < j->hi; i++) {
+            size_t src = j->bit_reverse ? ntt4_reverse_index(i, j->n) : i;
+            for (uint32_t c = 0; c < j->n_cols; c++) elem_as_bytes_be(j->columns + ((size_t)c * j->n + src) * 4, 4, row + (size_t)c * 32);
+            orc_keccak256(row, (size_t)j->n_cols * 32, leaves + i * 32);
+        }
+        free(row);
+    } else {
+        for (size_t k = j->lo; k < j->hi; k++) {
+            uint8_t buf[64];
+            memcpy(buf, j->nodes + (j->level_begin + 2 * k) * 32, 32);
+            memcpy(buf + 32, j->nodes + (j->level_begin + 2 * k + 1) * 32, 32);
+            orc_keccak256(buf, 64, j->nodes + (j->new_begin + k) * 32);
+        }
+    }
+    return NULL;
+}
+static void mk_run(mk_job *proto, size_t count, int threads) {
+    pthread_t th[64];
+    mk_job jobs[64];
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (count < 4096) threads = 1;
+    size_t per = (count + threads - 1) / threads;
+    int started = 0;
+    for (int t = 0; t < threads; t++) {
+        size_t lo = (size_t)t * per, hi = lo + per < count ? lo + per : count;
+        if (lo >= hi) break;
+        jobs[t] = *proto;
+        jobs[t].lo = lo;
+        jobs[t].hi = hi;
+        pthread_create(&th[t], NULL, mk_worker, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+int orc_merkle_commit_columns_mt(const u64 *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out, int threads) {
+    const size_t n = (size_t)1 << log2n;
+    mk_job j = { columns, n_cols, n, bit_reverse, nodes_out, 0, 0, 0, 0, 1 };
+    mk_run(&j, n, threads);
+    size_t level_begin = n - 1, level_end = 2 * level_begin;
+    while (level_begin != level_end) {
+        size_t new_begin = level_begin / 2;
+        j.leaves = 0;
+        j.level_begin = level_begin;
+        j.new_begin = new_begin;
+        mk_run(&j, level_begin - new_begin, threads);
+        level_end = level_begin - 1;
+        level_begin = new_begin;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ FRI fold
+   commit_phase's `FieldElement::<F>::from(2) * fold_polynomial(&current_poly, &zeta)` (provers/stark/src/fri/mod.rs:49):
+   fold_polynomial (fri/fri_functions.rs:7-30) = even coefficients + zeta * odd coefficients, each side built with
+   Polynomial::new (trailing zeros stripped) and padded to the longer one.  out: ceil(n/2) elements (all written);
+   *out_len = length after Polynomial::new strips the product's trailing zeros.  4-limb fields. */
+int orc_fri_fold_twice(int field, const u64 *coeffs, size_t n, const u64 *zeta, u64 *out, size_t *out_len) {
+    const orc_field *f = field_by_id(field);
+    if (!f || f->n != 4) return ORC_ERR_BAD_ARG;
+    size_t clen = poly_coeff_len(field, coeffs, n);   /* current_poly is a Polynomial: already stripped */
+    size_t n_out = (n + 1) / 2;
+    u64 two[4];
+    fp_from_u64(f, 4, two, 2);
+    for (size_t i = 0; i < n_out; i++) {
+        u64 even[4] = {0, 0, 0, 0}, odd[4] = {0, 0, 0, 0}, sum[4];
+        if (2 * i < clen) ui_copy(even, coeffs + 8 * i, 4);
+        if (2 * i + 1 < clen) fp_mul(f, 4, odd, coeffs + 8 * i + 4, zeta);
+        fp_add(f, 4, sum, even, odd);
+        fp_mul(f, 4, out + 4 * i, two, sum);
+    }
+    if (out_len) *out_len = poly_coeff_len(field, out, n_out);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ Groth16 quotient
+   QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) after
+   scale_and_accumulate_variable_polynomials has summed the variable polynomials into L, R, O (ncoeffs coefficients each):
+   l, r, o = evaluate_offset_fft(., 1, Some(2g), 7); t = evaluate_offset_fft(x^g - 1, 1, Some(2g), 7) then
+   inplace_batch_inverse (field/element.rs:47-65); h_evaluated = (l*r - o)*t; interpolate_offset_fft(h_evaluated, 7).
+   out: 2g elements; *coeff_len: length after Polynomial::new. */
+int orc_groth16_h_coefficients(const u64 *l, const u64 *r, const u64 *o, size_t ncoeffs, size_t gates, u64 *out, size_t *coeff_len) {
+    const int F = ORC_F_FR381;
+    const orc_field *f = field_by_id(F);
+    const size_t deg = 2 * gates;
+    if (gates == 0 || (gates & (gates - 1))) return ORC_ERR_INPUT_NOT_POW2;
+    u64 offset[4];
+    fp_from_u64(f, 4, offset, 7);   /* ORDER_R_MINUS_1_ROOT_UNITY (provers/groth16/src/common.rs:26) */
+    u64 *ev = (u64 *)malloc(4 * deg * 32), *tp = (u64 *)calloc(gates + 1, 32), *prefix = (u64 *)malloc(deg * 32);
+    if (!ev || !tp || !prefix) { free(ev); free(tp); free(prefix); return ORC_ERR_ALLOC; }
+    u64 *le = ev, *re = ev + 4 * deg, *oe = ev + 8 * deg, *t = ev + 12 * deg;
+    size_t len = 0;
+    int rc = orc_evaluate_fft(F, l, ncoeffs, 1, deg, offset, le, &len);
+    if (!rc) rc = orc_evaluate_fft(F, r, ncoeffs, 1, deg, offset, re, &len);
+    if (!rc) rc = orc_evaluate_fft(F, o, ncoeffs, 1, deg, offset, oe, &len);
+    /* t_poly = new_monomial(1, g) - 1 */
+    fp_neg(f, 4, tp, f->one);
+    ui_copy(tp + 4 * gates, f->one, 4);
+    if (gates == 0) rc = ORC_ERR_BAD_ARG;
+    if (!rc) rc = orc_evaluate_fft(F, tp, gates + 1, 1, deg, offset, t, &len);
+    if (!rc) {   /* inplace_batch_inverse */
+        ui_copy(prefix, t, 4);
+        for (size_t i = 1; i < deg; i++) fp_mul(f, 4, prefix + 4 * i, prefix + 4 * (i - 1), t + 4 * i);
+        u64 bi[4], ai[4], nx[4];
+        if (fp_inv(f, 4, bi, prefix + 4 * (deg - 1))) rc = ORC_ERR_INV_ZERO;
+        for (size_t i = deg - 1; !rc && i >= 1; i--) {
+            fp_mul(f, 4, ai, bi, prefix + 4 * (i - 1));
+            fp_mul(f, 4, nx, bi, t + 4 * i);
+            ui_copy(bi, nx, 4);
+            ui_copy(t + 4 * i, ai, 4);
+        }
+        if (!rc) ui_copy(t, bi, 4);
+    }
+    if (!rc) {
+        for (size_t i = 0; i < deg; i++) {
+            u64 p[4], d[4];
+            fp_mul(f, 4, p, le + 4 * i, re + 4 * i);
+            fp_sub(f, 4, d, p, oe + 4 * i);
+            fp_mul(f, 4, le + 4 * i, d, t + 4 * i);
+        }
+        rc = orc_interpolate_fft(F, le, deg, offset, out, coeff_len);
+    }
+    free(ev); free(tp); free(prefix);
+    return rc;
+}

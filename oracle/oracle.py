@@ -384,13 +384,37 @@ def keccak256(data: bytes) -> bytes:
     return out.tobytes()
 
 
-def merkle_commit_columns(columns, bit_reverse=True):
+def merkle_commit_columns(columns, bit_reverse=True, threads=1):
     """columns: (n_cols, N, 4) uint64, natural-order LDE columns -> nodes array ((2N-1), 32) uint8, root = nodes[0]
-    (BatchedMerkleTree over the rows of the bit-reverse-permuted columns, provers/stark/src/prover.rs:229-244)."""
+    (BatchedMerkleTree over the rows of the bit-reverse-permuted columns, provers/stark/src/prover.rs:229-244).
+    threads > 1 splits the (independent) hashes of the leaves and of every level over worker threads."""
     cols = np.ascontiguousarray(columns, dtype=np.uint64)
     n_cols, n = cols.shape[0], cols.shape[1]
     log2n = n.bit_length() - 1
     assert 1 << log2n == n
     nodes = np.zeros((2 * n - 1, 32), np.uint8)
-    _chk(lib().orc_merkle_commit_columns(_p(cols), n_cols, log2n, 1 if bit_reverse else 0, _p(nodes)))
+    if threads > 1:
+        _chk(lib().orc_merkle_commit_columns_mt(_p(cols), n_cols, log2n, 1 if bit_reverse else 0, _p(nodes), threads))
+    else:
+        _chk(lib().orc_merkle_commit_columns(_p(cols), n_cols, log2n, 1 if bit_reverse else 0, _p(nodes)))
     return nodes
+
+
+def fri_fold_twice(field, coeffs, zeta, strip=True):
+    """2 * fold_polynomial(p, zeta) (provers/stark/src/fri/mod.rs:49, fri/fri_functions.rs:7-30) on 4-limb elements."""
+    a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    z = np.ascontiguousarray(zeta, dtype=np.uint64).reshape(4)
+    out = np.zeros(((a.shape[0] + 1) // 2, 4), np.uint64)
+    olen = C.c_size_t(0)
+    _chk(lib().orc_fri_fold_twice(field, _p(a), C.c_size_t(a.shape[0]), _p(z), _p(out), C.byref(olen)))
+    return out[:olen.value] if strip else out
+
+
+def groth16_h_coefficients(l, r, o, gates, strip=True):
+    """QuadraticArithmeticProgram::calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) on the accumulated L, R, O."""
+    arrs = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in (l, r, o)]
+    out = np.zeros((2 * gates, 4), np.uint64)
+    clen = C.c_size_t(0)
+    _chk(lib().orc_groth16_h_coefficients(_p(arrs[0]), _p(arrs[1]), _p(arrs[2]), C.c_size_t(arrs[0].shape[0]), C.c_size_t(gates), _p(out),
+                                          C.byref(clen)))
+    return out[:clen.value] if strip else out

@@ -148,6 +148,13 @@ extern "C" {
     pub fn lw_stark_fri_layer(field: Field, coeffs: *const c_void, n_coeffs: usize, zeta: *const c_void, coset_offset: *const c_void,
                               domain_size: usize, out_poly: *mut c_void, out_poly_len: *mut usize, out_evaluation: *mut c_void,
                               out_root: *mut u8, out_nodes_or_null: *mut u8) -> c_int;
+    pub fn lw_stark_fri_layer_device(field: Field, d_coeffs: *const c_void, n_coeffs: usize, zeta: *const c_void,
+                                     coset_offset: *const c_void, domain_size: usize, d_out_poly: *mut c_void,
+                                     d_out_evaluation_or_null: *mut c_void, d_nodes_or_null: *mut c_void, out_root_or_null: *mut u8,
+                                     hip_stream: *mut c_void) -> c_int;
+    pub fn lw_groth16_h_coefficients_device(d_l: *const c_void, d_r: *const c_void, d_o: *const c_void, n_coeffs: usize,
+                                            num_gates: usize, d_out_h: *mut c_void, coeff_len_or_null: *mut usize,
+                                            hip_stream: *mut c_void) -> c_int;
     pub fn lw_groth16_h_coefficients(l_coeffs: *const c_void, r_coeffs: *const c_void, o_coeffs: *const c_void, n_coeffs: usize,
                                      num_gates: usize, out_h: *mut c_void, coeff_len: *mut usize) -> c_int;
 
@@ -170,6 +177,8 @@ extern "C" {
     pub fn lw_hip_msm_srs_device(srs: *const lw_srs_t, d_scalars: *const u64, n_scalars: usize, out_point_host: *mut c_void,
                                  hip_stream: *mut c_void) -> c_int;
     pub fn lw_hip_msm_srs_fr(srs: *const lw_srs_t, fr_elements: *const u64, n_scalars: usize, out_point: *mut c_void) -> c_int;
+    pub fn lw_hip_msm_srs_fr_device(srs: *const lw_srs_t, d_fr_elements: *const u64, n_scalars: usize, out_point_host: *mut c_void,
+                                    hip_stream: *mut c_void) -> c_int;
 }
 
 // The C structs above must keep the sizes the header gives them.

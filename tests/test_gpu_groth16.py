@@ -10,18 +10,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def oracle_h(l, r, o, gates):
-    f = O.F_FR381
-    off = O.elems_to_mont(f, [7])[0]
-    deg = 2 * gates
-    le, re_, oe = (O.evaluate_fft(f, x, 1, deg, off) for x in (l, r, o))
-    p = D.P_FR381
-    # t_poly = x^gates - 1 evaluated on the coset (qap.rs:21-25), then batch inverse
-    coeffs = [p - 1] + [0] * (gates - 1) + [1]
-    t = O.evaluate_fft(f, O.elems_to_mont(f, coeffs), 1, deg, off)
-    lc, rc, oc, tc = (O.elems_from_mont(f, x) for x in (le, re_, oe, t))
-    h = [((a * b - c) * pow(d, -1, p)) % p for a, b, c, d in zip(lc, rc, oc, tc)]
-    return O.interpolate_fft(f, O.elems_to_mont(f, h), off, strip=True)
+oracle_h = util.groth16_h_by_composition
 
 
 @pytest.mark.parametrize("gates", [1, 2, 8, 64, 512])

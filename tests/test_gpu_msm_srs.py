@@ -158,6 +158,23 @@ def test_folded_srs_matches_oracle_small(name, n, monkeypatch):
     srs.close()
 
 
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 4096), ("bn254_g1", 5000)])
+def test_folded_srs_single_bucket_holds_every_window(name, n, monkeypatch):
+    """A folded SRS sorts the items of ALL windows into one bucket set, so a bucket can hold n * W items, not n: every scalar
+    with the same digit in every window (sum_w 2^(20 w): bucket 0 receives 13 n items; 2^20 + 1: two windows' worth) needs
+    more rounds of partial sums than a plain MSM of n points — the workspace is sized for that (msm_core.cuh run)."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    _, points = util.msm_case(oid, n, 4100 + n)
+    monkeypatch.setenv("LW_HIP_SRS_FOLD_MIN", "0")
+    srs = msm.Srs(crv, points)
+    for k in (sum(1 << (20 * w) for w in range(13)), (1 << 20) + 1, sum((1 << 19) << (20 * w) for w in range(12))):
+        scalars = O.ints_to_array([k] * n, 4)
+        exp = O.parallel_msm_with(oid, scalars, points, 8, 16)
+        assert aff(oid, srs.msm(scalars)) == aff(oid, exp), hex(k)
+    srs.close()
+
+
 def test_folded_srs_matches_oracle_at_default_threshold():
     """2^19 points: the smallest set that is folded by default (BLS12-381 G1), against the oracle."""
     from lambda_elliptic_curves_amd import msm

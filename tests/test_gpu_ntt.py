@@ -166,7 +166,7 @@ def test_gen_twiddles_and_bitrev_permutation_match_oracle(name):
 
 
 @pytest.mark.parametrize("name", F256)
-@pytest.mark.parametrize("log_m,blow", [(1, 1), (3, 2), (6, 3), (9, 3), (12, 1), (13, 4), (16, 3), (17, 1)])
+@pytest.mark.parametrize("log_m,blow", [(0, 2), (1, 1), (3, 2), (6, 3), (9, 3), (12, 1), (13, 4), (16, 3), (17, 1)])
 def test_low_degree_extension_path(name, log_m, blow):
     # evaluate_offset_fft(poly, blowup, Some(n), offset) as the STARK prover calls it (provers/stark/src/prover.rs:150-167);
     # the device skips the stages that only replicate the zero-padded block — bytes must not change

@@ -52,6 +52,42 @@ def test_offset_blowup_domain(name, log_n, h, blowup):
 
 
 @pytest.mark.parametrize("name", BB)
+@pytest.mark.parametrize("log_m,blow", [(0, 3), (1, 1), (3, 2), (6, 3), (9, 3), (12, 1), (13, 4), (16, 3), (17, 1), (20, 2)])
+def test_low_degree_extension_path(name, log_m, blow):
+    """BASELINE config 4 is a STARK LDE: evaluate_offset_fft(poly, blowup, Some(n), offset) (provers/stark/src/prover.rs:150-167,
+    math/src/fft/polynomial.rs:30-38,74-82).  The device skips the log2(blowup) stages that only replicate the zero-padded
+    block and never materialises the padding — the bytes must equal the oracle's padded transform, for every layout, through
+    the host API (length rule) and through lw_hip_ntt_lde_device with a batch of 2."""
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()[name]
+    n = 1 << log_m
+    a = nz_last(name, util.rand_elems(name, n, 600 + log_m))
+    off = util.offset_elem(name, 3)
+    exp = O.evaluate_fft(oid, a, 1 << blow, n, off)
+    assert same(fft.evaluate_offset_fft(fld, a, 1 << blow, n, off), exp)
+    if log_m <= 16:
+        assert same(fft.evaluate_fft(fld, a, 1 << blow, n), O.evaluate_fft(oid, a, 1 << blow, n))
+        short = nz_last(name, a[: max(1, n - n // 3)].copy())
+        assert same(fft.evaluate_offset_fft(fld, short, 1 << blow, n, off), O.evaluate_fft(oid, short, 1 << blow, n, off))
+    b = util.rand_elems(name, n, 5)
+    two = np.concatenate([a, b])
+    words = 4 if name == "babybear_ext4" else 1
+    tdt = torch.int32 if name == "babybear_u32" else torch.int64
+    ndt = np.int32 if name == "babybear_u32" else np.int64
+    t_in = torch.from_numpy(two.view(ndt)).cuda()
+    N = n << blow
+    t_out = torch.empty((2 * N * words,), dtype=tdt, device="cuda")
+    fft.lde_device(fld, t_in, log_m, t_out, log_m + blow, batch=2, offset=off)
+    torch.cuda.synchronize()
+    got = t_out.cpu().numpy().view(two.dtype).reshape((2 * N,) + two.shape[1:])
+    assert same(got[:N], exp)
+    pad = np.zeros((N,) + two.shape[1:], two.dtype)
+    pad[:n] = b
+    assert same(got[N:], O.evaluate_fft(oid, pad, 1, N, off))
+
+
+@pytest.mark.parametrize("name", BB)
 def test_two_adicity_limit_and_errors(name):
     # TWO_ADICITY is declared 24 (babybear.rs:29, babybear_u32.rs:17): 2^25 has no root of unity in the reference
     from lambda_elliptic_curves_amd import errors, fft

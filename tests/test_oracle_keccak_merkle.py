@@ -63,3 +63,39 @@ def test_oracle_reproduces_the_reference_held_stone_compat_trace_commitments(kat
         have = {bytes(x).hex() for x in nodes}
         for h in case["auth_path_nodes"]:
             assert h in have, (case["name"], h)
+
+
+def test_threaded_merkle_equals_sequential():
+    cols = np.stack([util.rand_elems("stark252", 1 << 13, 77 + c) for c in range(3)])
+    assert np.array_equal(O.merkle_commit_columns(cols, True, threads=5), O.merkle_commit_columns(cols, True))
+    assert np.array_equal(O.merkle_commit_columns(cols[:1], False, threads=3), O.merkle_commit_columns(cols[:1], False))
+
+
+def test_fri_fold_restatement_matches_bigint_definition():
+    # 2 * fold_polynomial(p, zeta) (fri/mod.rs:49, fri_functions.rs:7-30): p'_i = 2 (c_2i + zeta c_2i+1), stripped
+    from oracle import bigint_def as D
+    f, p = O.F_STARK252, D.P_STARK252
+    for n in (1, 2, 7, 8, 33):
+        a = util.rand_elems("stark252", n, 300 + n)
+        zc = 0x1234567890abcdef1234567 + n
+        c = O.elems_from_mont(f, a)
+        exp = [(2 * (c[2 * i] + (zc * c[2 * i + 1] if 2 * i + 1 < n else 0))) % p for i in range((n + 1) // 2)]
+        while exp and exp[-1] == 0:
+            exp.pop()
+        got = O.fri_fold_twice(f, a, O.elems_to_mont(f, [zc])[0])
+        assert O.elems_from_mont(f, got) == exp
+    # cancellation: c1 = -c0 / zeta makes the folded coefficient zero -> stripped
+    zc = 5
+    c0 = 1234567
+    c1 = (-c0 * pow(zc, -1, p)) % p
+    a = O.elems_to_mont(f, [9, 1, c0, c1])
+    assert O.fri_fold_twice(f, a, O.elems_to_mont(f, [zc])[0]).shape[0] == 1
+
+
+def test_groth16_h_restatement_matches_composition():
+    for gates in (1, 2, 16, 128):
+        l, r, o = (util.rand_elems("fr381", gates, s + gates) for s in (70, 71, 72))
+        assert np.array_equal(O.groth16_h_coefficients(l, r, o, gates), util.groth16_h_by_composition(l, r, o, gates))
+    k = 5
+    l, r, o = (util.rand_elems("fr381", k, s) for s in (1, 2, 3))
+    assert np.array_equal(O.groth16_h_coefficients(l, r, o, 16), util.groth16_h_by_composition(l, r, o, 16))

@@ -104,3 +104,19 @@ def plonk_test_srs(oid, length, secret=2):
     g = generator(oid)
     r = D.P_FR381
     return np.stack([O.ec_mul(oid, g, pow(secret, i, r), 4) for i in range(length)])
+
+
+def groth16_h_by_composition(l, r, o, gates):
+    """calculate_h_coefficients (provers/groth16/src/qap.rs:15-39) as a composition of oracle transforms and Python
+    big-integer pointwise arithmetic — the independent check of O.groth16_h_coefficients at small sizes."""
+    from oracle import bigint_def as D
+    f = O.F_FR381
+    off = O.elems_to_mont(f, [7])[0]
+    deg = 2 * gates
+    le, re_, oe = (O.evaluate_fft(f, x, 1, deg, off) for x in (l, r, o))
+    p = D.P_FR381
+    coeffs = [p - 1] + [0] * (gates - 1) + [1]       # t_poly = x^gates - 1 (qap.rs:21-25), then batch inverse
+    t = O.evaluate_fft(f, O.elems_to_mont(f, coeffs), 1, deg, off)
+    lc, rc, oc, tc = (O.elems_from_mont(f, x) for x in (le, re_, oe, t))
+    h = [((a * b - c) * pow(d, -1, p)) % p for a, b, c, d in zip(lc, rc, oc, tc)]
+    return O.interpolate_fft(f, O.elems_to_mont(f, h), off, strip=True)

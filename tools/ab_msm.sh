@@ -1,3 +1,4 @@
+export LW_HIP_TUNING=1   # the library reads its A/B switches only with this set
 # quick MSM timing for the four groups (device-resident inputs); prints one line per (curve, log2n)
 python - <<'PY'
 import sys, time, numpy as np, torch

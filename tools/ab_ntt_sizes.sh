@@ -1,3 +1,4 @@
+export LW_HIP_TUNING=1   # the library reads its A/B switches only with this set
 # usage: ab_ntt_sizes.sh "L L ..." "VAR=val|-" ... : Stark252 NTT per size and setting
 Ls=$1; shift
 for kv in "$@"; do if [ "$kv" = "-" ]; then pre=""; else pre="$kv"; fi; for L in $Ls; do env $pre python bench.py --workload ntt --log2n $L --no-cpu-baseline --no-host-path --steps 30 --warmup 5 2>/dev/null | python -c "

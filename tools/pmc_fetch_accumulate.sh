@@ -1,3 +1,4 @@
+export LW_HIP_TUNING=1   # the library reads its A/B switches only with this set
 # usage: pmc_fetch_accumulate.sh TAG : FETCH_SIZE (KiB, raw) of the MSM accumulate kernel for the current environment
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d gpurun_out/pf_$1 -o pmc -- python3 bench.py --workload msm --no-cpu-baseline --no-host-path --steps 2 --warmup 1 > /dev/null 2>&1

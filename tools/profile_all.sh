@@ -1,4 +1,5 @@
 #!/bin/bash
+export LW_HIP_TUNING=1   # the library reads its A/B switches only with this set
 # Regenerates everything under profiles/ that bench.py's numbers are checked against.  Run on the GPU box from the
 # repository root (gpurun -- 'bash tools/profile_all.sh TAG'); outputs land in gpurun_out/prof_TAG/ and the summaries
 # are copied to profiles/ by hand afterwards.  Counter passes are separate runs with --kernel-trace only.
