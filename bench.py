@@ -46,6 +46,17 @@ def latest_profile(pattern):
     return files[-1] if files else None
 
 
+def measured_rate(label, default):
+    """(rate in products/s, source) of a `RATE <label> <x> Gmul/s` line in the newest committed profiles/rNN_microbench.txt."""
+    import re
+    path = latest_profile("microbench.txt")
+    if path:
+        m = re.search(r"RATE %s\s+([0-9.]+) Gmul/s" % re.escape(label), open(path).read())
+        if m:
+            return float(m.group(1)) * 1e9, "profiles/%s (%s, all CUs)" % (os.path.basename(path), label)
+    return default, "default (no profiles/rNN_microbench.txt)"
+
+
 def pmc_counter(kernel_substr, counter):
     """Launch-weighted mean of a counter for a kernel from the newest committed rocprofv3 counter summary, or None."""
     import csv
@@ -203,6 +214,7 @@ def main():
         alg_bytes_per_launch = 2.0 * n_local_ntt * 32 / max(passes, 1)     # 2*N*B per transform, spread over its passes
         achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic, traffic_src = traffic_entry("ntt", L)
+        mul_peak, mul_peak_src = measured_rate("fe_mul Stark252", 182.5e9)
         result.update({
             "metric": "NTT elems/sec (Stark252 radix-2, 2^%d, forward, bit-exact vs CPU: see 'bit_exact') "
                       "[+ MSM G1 point-adds/sec under 'msm']" % L,
@@ -221,8 +233,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "note": "256-bit NTT is integer-VALU bound (see 'valu'); HBM fraction reported as required"},
             "valu": {"modmul_per_s": (n // 2) * L * args.steps * world / dt, "unit": "Montgomery products/s",
-                     "peak_measured": 182.5e9 * world, "peak_source": "profiles/r01_microbench.txt (fe_mul Stark252, all CUs)",
-                     "frac": (n // 2) * L * args.steps / dt / 182.5e9,
+                     "peak_measured": mul_peak * world, "peak_source": mul_peak_src,
+                     "frac": (n // 2) * L * args.steps / dt / mul_peak,
                      "valu_busy_pmc": pmc_counter("ntt_pass_kernel", "VALUBusy"),
                      "note": "the bound that applies: products/s against the measured product rate of the MAC pipe; "
                              "valu_busy_pmc = rocprofv3 VALUBusy (%) from the newest profiles/rNN_pmc_summary.csv"},

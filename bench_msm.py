@@ -280,8 +280,9 @@ def run_msm_leg(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm, 
                  "unit": "bucket additions/s", "device_adds_per_msm": dev_adds, "device_window_bits": dev_c,
                  "accumulate_ms_per_msm": acc_ms / steps if acc_ms else None,
                  # the first-round kernel over the normalised points (template arguments <curve, waves, AFFINE = true>)
-                 "valu_busy_pmc": pmc_counter("msm_accumulate_kernel<lw::Bls12381G1, 2, true>", "VALUBusy")
-                 or pmc_counter("msm_accumulate", "VALUBusy")},
+                 "valu_busy_pmc": pmc_counter("msm_accumulate_kernel<lw::Bls12381G1Iso, 2, true>", "VALUBusy"),
+                 "valu_busy_kernel": "msm_accumulate_kernel<lw::Bls12381G1Iso, 2, true> (first round, normalised points on the "
+                                     "isomorphic curve) in the newest profiles/rNN_pmc_summary.csv"},
         "kernel_times_ms": {k: {"launches": v[0], "avg_ms": v[1] / max(v[0], 1)} for k, v in prof.items()},
         "cpu_baseline": cpu, "cpu_all_cores": cpu_all, "bit_exact": bit_exact, "host_path": host_path, "srs_path": srs_path,
     }

@@ -202,6 +202,13 @@ int lw_hip_ntt_sharded_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir
 int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
                                        uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output,
                                        void *hip_stream);
+/* Self-test hook: the same run cut after step `stop_after` of the schedule (1 exchange A, 2 cross step, 3 exchange C,
+ * 4 local NTT, 5 exchange E, 6 interleave): block g of d_out_full receives the batch x M elements virtual rank g holds at
+ * that point.  tests/test_gpu_distributed.py checks the Python transliteration of the schedule
+ * (lambda_elliptic_curves_amd/distributed.py, the one the world-size-2 gloo test drives) against it step by step. */
+int lw_hip_ntt_sharded_selftest_steps_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                                             uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output,
+                                             int stop_after, void *hip_stream);
 /* msm over points sharded across the ranks: every rank passes its n_local (scalar, point) pairs (n_local may differ
  * per rank, 0 allowed); each runs the full Pippenger on its shard, the G partial sums are all-gathered (one point
  * each) and added.  Every rank receives the sum over all ranks' pairs, normalised like lw_hip_msm. */

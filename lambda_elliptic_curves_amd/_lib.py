@@ -29,7 +29,8 @@ EXPORTS = [
     "lw_hip_msm_srs_fr", "lw_hip_msm_srs_fr_device", "lw_stark_fri_layer_device", "lw_groth16_h_coefficients_device",
     "lw_hip_ec_add_outer_device",
     "lw_hip_comm_unique_id", "lw_hip_comm_init", "lw_hip_comm_shutdown", "lw_hip_comm_info",
-    "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_msm_sharded_device",
+    "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_ntt_sharded_selftest_steps_device",
+    "lw_hip_msm_sharded_device",
 ]
 
 
@@ -145,6 +146,8 @@ def lib():
     L.lw_hip_ntt_sharded_device.restype = i
     L.lw_hip_ntt_sharded_selftest_device.argtypes = [i, i, i, vp, vp, u32, u32, u32, i, vp]
     L.lw_hip_ntt_sharded_selftest_device.restype = i
+    L.lw_hip_ntt_sharded_selftest_steps_device.argtypes = [i, i, i, vp, vp, u32, u32, u32, i, i, vp]
+    L.lw_hip_ntt_sharded_selftest_steps_device.restype = i
     L.lw_hip_msm_sharded_device.argtypes = [i, vp, vp, sz, vp, vp]
     L.lw_hip_msm_sharded_device.restype = i
     _lib = L

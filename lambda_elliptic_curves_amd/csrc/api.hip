@@ -154,6 +154,9 @@ void Context::release_all() {
     spans.clear();
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     event_pool.clear();
+    for (hipEvent_t e : sync_pool) (void)hipEventDestroy(e);
+    sync_pool.clear();
+    shard_prepared_key = 0;
     profiling = false;
     host_io_a.release();
     host_io_b.release();

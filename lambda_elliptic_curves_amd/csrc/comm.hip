@@ -116,6 +116,9 @@ struct Transport {
     int first = 0, nlocal = 1;   // ranks [first, first + nlocal) live in this process
     virtual int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
                            hipStream_t s) = 0;
+    // collective agreement on a local status: LW_OK only if every rank passed LW_OK, else LW_ERR_COMM on all of them
+    // (the failing rank reports its own code); synchronises `s`
+    virtual int agree(int local_status, hipStream_t s) = 0;
     virtual ~Transport() {}
 };
 
@@ -137,6 +140,20 @@ struct RcclTransport : Transport {
         LW_NCCL_CHECK(g_rccl.GroupEnd());
         return LW_OK;
     }
+    int agree(int local_status, hipStream_t s) override {
+        Context &c = ctx();
+        if (c.small.ensure(8 * (size_t)(G + 1))) return LW_ERR_ALLOC;   // (an allocation of 72 bytes: if this fails nothing works)
+        int64_t mine = local_status, all[9] = {0};
+        int64_t *d = (int64_t *)c.small.p;
+        LW_HIP_CHECK(hipMemcpyAsync(d, &mine, 8, hipMemcpyHostToDevice, s), LW_ERR_LAUNCH);
+        LW_NCCL_CHECK(g_rccl.AllGather(d, d + 1, 8, ncclChar, g_comm.comm, s));
+        LW_HIP_CHECK(hipMemcpyAsync(all, d + 1, 8 * (size_t)G, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
+        if (local_status) return local_status;
+        for (int g = 0; g < G; g++)
+            if (all[g]) { set_error("rank %d failed to prepare the sharded call (status %lld)", g, (long long)all[g]); return LW_ERR_COMM; }
+        return LW_OK;
+    }
 };
 
 struct SimTransport : Transport {   // G virtual ranks on one device
@@ -151,6 +168,7 @@ struct SimTransport : Transport {   // G virtual ranks on one device
                                                 hipMemcpyDeviceToDevice, s), LW_ERR_LAUNCH);
         return LW_OK;
     }
+    int agree(int local_status, hipStream_t) override { return local_status; }   // all virtual ranks share one status
 };
 
 // ---------------------------------------------------------------- step F: local interleave
@@ -185,10 +203,42 @@ static int launch_interleave(Context &c, size_t eb, const void *in, void *out, u
 }
 
 // ---------------------------------------------------------------- the schedule
+// Cross-stream dependencies of one call: events (no timing) taken from a context pool and handed back at the end.
+struct SyncEvents {
+    Context &c;
+    std::vector<hipEvent_t> taken;
+    explicit SyncEvents(Context &cc) : c(cc) {}
+    hipEvent_t get() {
+        hipEvent_t e = nullptr;
+        if (!c.sync_pool.empty()) { e = c.sync_pool.back(); c.sync_pool.pop_back(); }
+        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        taken.push_back(e);
+        return e;
+    }
+    ~SyncEvents() { for (hipEvent_t e : taken) c.sync_pool.push_back(e); }
+};
+// `to` waits for everything enqueued on `from` so far
+static int chain(SyncEvents &ev, hipStream_t from, hipStream_t to) {
+    hipEvent_t e = ev.get();
+    if (!e) { set_error("hipEventCreate failed"); return LW_ERR_LAUNCH; }
+    LW_HIP_CHECK(hipEventRecord(e, from), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamWaitEvent(to, e, 0), LW_ERR_LAUNCH);
+    return LW_OK;
+}
+int ensure_aux_stream(Context &c);   // msm.hip: the context's side stream
+
 // in[i] / out[i]: buffers of local rank first + i; batch entries in_bstride / out_bstride elements apart.
+//
+// Steps per batch column:  1 A exchange   2 B cross step   3 C exchange   4 D local NTT   [5 E exchange   6 F interleave].
+// The exchanges run on the context's side stream, the kernels on the caller's stream, one column at a time, enqueued
+// diagonal by diagonal (A of column d, C of column d-1, E of column d-2, each followed by its kernel): while column k's
+// cross step or local transform runs, column k+1's slices are already on the links — BASELINE config 4 has four columns.
+// A single column (batch = 1) degenerates to the serial order.
+// stop_after (self-test only, 0 = all): run steps 1..stop_after and hand the buffer that step wrote (batch x M elements per
+// rank, dense) to out[] — tests/test_gpu_distributed.py compares the Python transliteration with it step by step.
 static int ntt_sharded_run(Context &c, Transport &tp, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const char *const *in,
                            char *const *out, uint64_t in_bstride, uint64_t out_bstride, uint32_t L, uint32_t batch, int natural,
-                           hipStream_t s) {
+                           hipStream_t s, int stop_after = 0) {
     const int G = tp.G;
     uint32_t lg = 0;
     while ((1 << lg) < G) lg++;
@@ -204,61 +254,82 @@ static int ntt_sharded_run(Context &c, Transport &tp, lw_field_t field, lw_layou
     const uint64_t M = 1ull << (L - lg), sl = M >> lg;
     const int nl = tp.nlocal;
     const size_t per_rank = (size_t)batch * M * eb;
-    if (c.shard_a.ensure(per_rank * nl) || c.shard_b.ensure(per_rank * nl)) return LW_ERR_ALLOC;
+    // Everything that can fail for lack of memory is taken BEFORE the first exchange and the outcome is agreed on by all
+    // ranks (one tiny all-gather, first call of a shape only): a rank that returned early would leave the others blocked
+    // in the collective.  Later local failures (launch errors) do not skip exchanges either, see below.
+    int prep = LW_OK;
+    if (c.shard_a.ensure(per_rank * nl) || c.shard_b.ensure(per_rank * nl) || c.scratch.ensure((size_t)M * eb)) prep = LW_ERR_ALLOC;
+    if (!prep) prep = ensure_aux_stream(c);
+    const uint64_t shape_key = ((uint64_t)field << 60) ^ ((uint64_t)layout << 56) ^ ((uint64_t)dir << 52) ^ ((uint64_t)L << 40) ^
+                               ((uint64_t)batch << 8) ^ (uint64_t)G ^ ((uint64_t)(natural != 0) << 48);
+    if (prep || c.shard_prepared_key != shape_key) {
+        int rc0 = tp.agree(prep, s);
+        if (rc0) return rc0;
+        c.shard_prepared_key = shape_key;
+    }
+    hipStream_t cs = c.aux_stream;   // exchanges
     std::vector<const char *> src(nl);
-    std::vector<char *> a(nl), b(nl);
+    std::vector<char *> a(nl), b(nl), dst(nl);
     for (int i = 0; i < nl; i++) {
         a[i] = (char *)c.shard_a.p + per_rank * i;
         b[i] = (char *)c.shard_b.p + per_rank * i;
     }
-    int rc;
+    int rc = LW_OK, local_rc = LW_OK;
     if (G == 1) {   // degenerate: one exchange with myself, so that a 1-rank communicator still exercises the transport
-        if (in_bstride != M) {
-            set_error("1-rank sharded NTT needs a dense batch");
-            return LW_ERR_BAD_ARG;
-        }
-        rc = tp.all_to_all(in, a.data(), M * eb, batch, M * eb, s);
-        if (rc) return rc;
-        return ntt_device_locked(c, field, layout, dir, a[0], out[0], L, batch, out_bstride, nullptr, s, 0xffffffffu);
-    }
-    // A: slice h of my block -> rank h.  The caller's batch stride applies to the send side only, so strided inputs
-    // (the simulator's full-vector layout) are first exchanged batch entry by batch entry.
-    if (in_bstride == M) {
-        rc = tp.all_to_all(in, a.data(), sl * eb, batch, M * eb, s);
-        if (rc) return rc;
-    } else {
         for (uint32_t bi = 0; bi < batch; bi++) {
-            std::vector<const char *> s1(nl);
-            std::vector<char *> r1(nl);
-            for (int i = 0; i < nl; i++) { s1[i] = in[i] + (size_t)bi * in_bstride * eb; r1[i] = a[i] + (size_t)bi * M * eb; }
-            rc = tp.all_to_all(s1.data(), r1.data(), sl * eb, 1, 0, s);
+            const char *s1[1] = {in[0] + (size_t)bi * in_bstride * eb};
+            char *r1[1] = {a[0] + (size_t)bi * M * eb};
+            rc = tp.all_to_all(s1, r1, M * eb, 1, 0, s);
             if (rc) return rc;
         }
+        return ntt_device_locked(c, field, layout, dir, a[0], out[0], L, batch, out_bstride, nullptr, s, 0xffffffffu);
     }
-    // B: cross-shard step on my j2 slice [g*sl, (g+1)*sl)
-    for (int i = 0; i < nl; i++) {
-        const uint64_t g = (uint64_t)(tp.first + i);
-        rc = ntt_cross_device(c, field, layout, dir, a[i], b[i], L, lg, g * sl, sl, sl, batch, M, s);
-        if (rc) return rc;
-    }
-    // C: row k1 -> rank k1
-    for (int i = 0; i < nl; i++) src[i] = b[i];
-    rc = tp.all_to_all(src.data(), a.data(), sl * eb, batch, M * eb, s);
+    const int last_step = stop_after > 0 ? stop_after : (natural ? 6 : 4);
+    const int nex = natural ? 3 : 2;                        // exchanges per column
+    SyncEvents ev(c);
+    rc = chain(ev, s, cs);                                  // the caller's input is ready once `s` gets here
     if (rc) return rc;
-    // D: local M-point transform: z[k2] = X[g + G*k2]
-    for (int i = 0; i < nl; i++) {
-        rc = natural ? ntt_device_locked(c, field, layout, dir, a[i], b[i], L - lg, batch, M, nullptr, s, 0xffffffffu)
-                     : ntt_device_locked(c, field, layout, dir, a[i], out[i], L - lg, batch, out_bstride, nullptr, s, 0xffffffffu);
-        if (rc) return rc;
+    const bool d_direct = !natural && out_bstride == M;     // step D may write straight into the caller's buffer
+    for (uint32_t d = 0; d < batch + (uint32_t)nex - 1; d++) {
+        for (int st = 0; st < nex; st++) {
+            if (d < (uint32_t)st || d - st >= batch) continue;
+            const uint32_t bi = d - (uint32_t)st;
+            const size_t boff = (size_t)bi * M * eb;
+            const int ex_step = 2 * st + 1, k_step = 2 * st + 2;
+            if (ex_step > last_step) continue;
+            // ---- exchange `st` of column bi on the side stream (after the kernel that produced its payload)
+            if (st > 0) { rc = chain(ev, s, cs); if (rc) return rc; }
+            for (int i = 0; i < nl; i++) {
+                src[i] = st == 0 ? in[i] + (size_t)bi * in_bstride * eb : b[i] + boff;
+                dst[i] = a[i] + boff;
+            }
+            rc = tp.all_to_all(src.data(), dst.data(), sl * eb, 1, 0, cs);
+            if (rc) return rc;                              // a failing collective is fatal for the communicator anyway
+            rc = chain(ev, cs, s);
+            if (rc) return rc;
+            if (k_step > last_step || local_rc) continue;   // after a local failure: keep exchanging, stop computing
+            // ---- its kernel on the caller's stream
+            for (int i = 0; i < nl && !local_rc; i++) {
+                const uint64_t g = (uint64_t)(tp.first + i);
+                if (st == 0)        // B: cross-shard step on my j2 slice [g*sl, (g+1)*sl)
+                    local_rc = ntt_cross_device(c, field, layout, dir, a[i] + boff, b[i] + boff, L, lg, g * sl, sl, sl, 1, M, s);
+                else if (st == 1)   // D: local M-point transform: z[k2] = X[g + G*k2]
+                    local_rc = ntt_device_locked(c, field, layout, dir, a[i] + boff,
+                                                 d_direct && !stop_after ? out[i] + (size_t)bi * out_bstride * eb : b[i] + boff, L - lg, 1, 0,
+                                                 nullptr, s, 0xffffffffu);
+                else                // F: interleave into natural order
+                    local_rc = launch_interleave(c, eb, a[i] + boff, stop_after ? b[i] + boff : out[i] + (size_t)bi * out_bstride * eb, lg, sl,
+                                                 1, M, M, s);
+            }
+        }
     }
-    if (!natural) return LW_OK;
-    // E: slice h of my cyclic shard -> rank h;  F: interleave into natural order
-    for (int i = 0; i < nl; i++) src[i] = b[i];
-    rc = tp.all_to_all(src.data(), a.data(), sl * eb, batch, M * eb, s);
-    if (rc) return rc;
-    for (int i = 0; i < nl; i++) {
-        rc = launch_interleave(c, eb, a[i], out[i], lg, sl, batch, M, out_bstride, s);
-        if (rc) return rc;
+    if (local_rc) return local_rc;
+    if (stop_after || (!natural && !d_direct)) {
+        // where the last executed step left its result: A, C, E -> a;  B, D, F(self-test) -> b
+        const bool in_a = stop_after && (last_step & 1);
+        for (int i = 0; i < nl; i++)
+            LW_HIP_CHECK(hipMemcpy2DAsync(out[i], out_bstride * eb, (in_a ? a[i] : b[i]), M * eb, M * eb, batch, hipMemcpyDeviceToDevice, s),
+                         LW_ERR_LAUNCH);
     }
     return LW_OK;
 }
@@ -345,8 +416,9 @@ int lw_hip_ntt_sharded_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir
     return ntt_sharded_run(en.c, tp, field, layout, dir, in, out, M, M, log2n_total, batch, natural_output, en.stream);
 }
 
-int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
-                                       uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output, void *hip_stream) {
+static int sharded_selftest(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                            uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output, int stop_after,
+                            void *hip_stream) {
     int rc = check_sharded_args(field, layout, dir, d_in_full, d_out_full, log2n_total);
     if (rc) return rc;
     if (log2_shards < 1 || log2_shards > 3) { set_error("self-test takes 2, 4 or 8 virtual ranks"); return LW_ERR_BAD_ARG; }
@@ -364,7 +436,18 @@ int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_
         in[g] = (const char *)d_in_full + (size_t)g * M * eb;
         out[g] = (char *)d_out_full + (size_t)g * M * eb;
     }
-    return ntt_sharded_run(en.c, tp, field, layout, dir, in.data(), out.data(), N, N, log2n_total, batch, natural_output, en.stream);
+    return ntt_sharded_run(en.c, tp, field, layout, dir, in.data(), out.data(), N, N, log2n_total, batch, natural_output, en.stream,
+                           stop_after);
+}
+int lw_hip_ntt_sharded_selftest_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                                       uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output, void *hip_stream) {
+    return sharded_selftest(field, layout, dir, d_in_full, d_out_full, log2n_total, log2_shards, batch, natural_output, 0, hip_stream);
+}
+int lw_hip_ntt_sharded_selftest_steps_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in_full, void *d_out_full,
+                                             uint32_t log2n_total, uint32_t log2_shards, uint32_t batch, int natural_output, int stop_after,
+                                             void *hip_stream) {
+    if (stop_after < 1 || stop_after > (natural_output ? 6 : 4)) { set_error("stop_after %d out of range", stop_after); return LW_ERR_BAD_ARG; }
+    return sharded_selftest(field, layout, dir, d_in_full, d_out_full, log2n_total, log2_shards, batch, natural_output, stop_after, hip_stream);
 }
 
 int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n_local, void *out_point_host,
@@ -375,17 +458,35 @@ int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const
     if (en.rc) return en.rc;
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     Context &c = en.c;
-    std::vector<char> part(pb), all(pb * g_comm.nranks);
-    int rc = msm_device(c, curve, d_scalars, d_points, n_local, part.data(), en.stream, 0, 0);
-    if (rc) return rc;
-    // all-gather of one point per rank, then <= 7 group additions on the host (same limb code as the device)
-    if (c.shard_a.ensure(pb * (g_comm.nranks + 1))) return LW_ERR_ALLOC;
-    char *d_send = (char *)c.shard_a.p, *d_recv = d_send + pb;
-    LW_HIP_CHECK(hipMemcpyAsync(d_send, part.data(), pb, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
-    LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, pb, ncclChar, g_comm.comm, en.stream));
-    LW_HIP_CHECK(hipMemcpyAsync(all.data(), d_recv, pb * g_comm.nranks, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+    const int G = g_comm.nranks;
+    // payload per rank: [status (8 bytes) | partial sum].  The local MSM runs first and its outcome travels WITH the point:
+    // a rank whose MSM failed still enters the all-gather (status != 0, identity payload), so nobody is left blocked in the
+    // collective, and every rank returns LW_ERR_COMM together.
+    const size_t slot = 8 + pb;
+    std::vector<char> mine(slot, 0), all(slot * G);
+    const int local_rc = msm_device(c, curve, d_scalars, d_points, n_local, mine.data() + 8, en.stream, 0, 0);
+    const int64_t st = local_rc;
+    memcpy(mine.data(), &st, 8);
+    if (local_rc) memset(mine.data() + 8, 0, pb);
+    if (c.shard_a.ensure(slot * (G + 1))) {
+        // cannot even stage 152 bytes: nothing to send — the peers will time out in RCCL; report it
+        return LW_ERR_ALLOC;
+    }
+    char *d_send = (char *)c.shard_a.p, *d_recv = d_send + slot;
+    LW_HIP_CHECK(hipMemcpyAsync(d_send, mine.data(), slot, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
+    LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, slot, ncclChar, g_comm.comm, en.stream));
+    LW_HIP_CHECK(hipMemcpyAsync(all.data(), d_recv, slot * G, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
     LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
-    return msm_sum_points_host(curve, all.data(), (size_t)g_comm.nranks, out_point_host);
+    if (local_rc) return local_rc;
+    std::vector<char> pts(pb * G);
+    for (int g = 0; g < G; g++) {
+        int64_t sg = 0;
+        memcpy(&sg, all.data() + slot * g, 8);
+        if (sg) { set_error("rank %d failed its local MSM (status %lld)", g, (long long)sg); return LW_ERR_COMM; }
+        memcpy(pts.data() + pb * g, all.data() + slot * g + 8, pb);
+    }
+    // <= 7 group additions on the host (same limb code as the device)
+    return msm_sum_points_host(curve, pts.data(), (size_t)G, out_point_host);
 }
 
 }  // extern "C"

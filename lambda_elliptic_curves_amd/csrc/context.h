@@ -100,6 +100,8 @@ struct Context {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     DeviceBuf shard_a, shard_b;       // exchange buffers of the sharded (multi-GPU) entry points
+    uint64_t shard_prepared_key = 0;  // shape of the last sharded NTT whose allocations every rank agreed on (comm.hip)
+    std::vector<hipEvent_t> sync_pool;   // untimed events for cross-stream dependencies inside one call
     void release_all();               // frees every cached device object (shutdown / device change)
 };
 

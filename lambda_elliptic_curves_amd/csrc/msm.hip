@@ -749,6 +749,22 @@ static int msm_normalize_min_log2(lw_curve_t curve) {
 }
 
 // affine_points: d_points are affine pairs produced by msm_normalize_device (2 field elements per row)
+// The context's side stream (MSM: normalisation beside the sort; sharded NTT: exchanges beside the kernels).
+int ensure_aux_stream(Context &c) {
+    if (c.aux_stream) return LW_OK;
+    // lowest priority: the sort on the caller's stream (2.7 ms alone) keeps its pace and the normalisation fills the
+    // issue slots it leaves; with equal priorities the sort kernels queued behind the normalisation's workgroups
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c.aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c.aux_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("cannot create the side stream");
+        return LW_ERR_LAUNCH;
+    }
+    return LW_OK;
+}
+
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points) {
     if (scalars_montgomery && n) {
@@ -779,17 +795,9 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
             int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
             if (rc) return rc;
         } else {
-        if (!c.aux_stream) {
-            // lowest priority: the sort on the caller's stream (2.7 ms alone) keeps its pace and the normalisation fills the
-            // issue slots it leaves; with equal priorities the sort kernels queued behind the normalisation's workgroups
-            int prio_lo = 0, prio_hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-            if (hipStreamCreateWithPriority(&c.aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-                hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c.aux_join, hipEventDisableTiming) != hipSuccess) {
-                set_error("cannot create the MSM side stream");
-                return LW_ERR_LAUNCH;
-            }
+        {
+            int rc = ensure_aux_stream(c);
+            if (rc) return rc;
         }
         LW_HIP_CHECK(hipEventRecord(c.aux_fork, stream), LW_ERR_LAUNCH);
         LW_HIP_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_fork, 0), LW_ERR_LAUNCH);

@@ -16,9 +16,10 @@ single-device API on the concatenated input.
 The production path is `HipComm`: the communicator and the whole exchange schedule live INSIDE the C library
 (csrc/comm.hip: lw_hip_comm_init, lw_hip_ntt_sharded_device, lw_hip_msm_sharded_device — RCCL send/recv groups and
 all-gather issued from C++), so a Rust caller reaches the multi-GPU path through the same extern "C" boundary and this
-module is only a thin caller.  `TorchDistComm` / `SimComm` run the same schedule in Python over torch.distributed (gloo
-on CPU for tests) or G in-process virtual ranks; `backend` abstracts their local compute (default: the HIP library;
-there is no CPU fallback).
+module is only a thin caller.  `TorchDistComm` / `SimComm` run a literal transliteration of that schedule in Python over
+torch.distributed (gloo on CPU for tests) or G in-process virtual ranks, checked against the C++ one step by step on
+the GPU (`ntt_sharded(..., stop_after=k)` vs `ntt_sharded_selftest_steps`); `backend` abstracts their local compute
+(default: the HIP library; there is no CPU fallback).
 """
 import ctypes as C
 
@@ -173,11 +174,17 @@ def _log2(n):
 
 
 # ---------------------------------------------------------------- sharded NTT
-def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, natural_output=True, batch=1):
-    """x_local: this rank's contiguous block of the natural-order vector, tensor [M, words] (M = N / G).
-    Returns this rank's block of the natural-order result (natural_output=True), or the cyclic shard
-    X[rank + G*k2] (one exchange fewer; convenient when a bit-reverse + commit follows).  `batch` > 1 (HipComm only):
-    x_local holds `batch` blocks of M elements back to back."""
+def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, natural_output=True, batch=1, stop_after=0):
+    """x_local: this rank's contiguous block of the natural-order vector, tensor [M, words] (M = N / G); `batch` > 1:
+    `batch` such blocks back to back.  Returns this rank's block of the natural-order result (natural_output=True), or the
+    cyclic shard X[rank + G*k2] (one exchange fewer; convenient when a bit-reverse + commit follows).
+
+    With a HipComm this is one call into the library (csrc/comm.hip ntt_sharded_run, RCCL).  With TorchDistComm / SimComm it
+    is the LITERAL TRANSLITERATION of that C++ schedule — same six steps per batch column, same chunk order in every
+    exchange, same (j2_begin, slice_len) arguments to the cross step — kept so that the world-size-2 gloo test
+    (tests/test_distributed_cpu.py) exercises the schedule across real processes on CPU.  `stop_after` = k returns the
+    buffer step k wrote, [batch, M, ...]; tests/test_gpu_distributed.py compares it with the C++ schedule's
+    (lw_hip_ntt_sharded_selftest_steps_device) after every step, so the two cannot drift apart."""
     if isinstance(comm, HipComm):   # production path: the schedule runs in C++ over the library's RCCL communicator
         import torch
         out = torch.empty_like(x_local)
@@ -185,6 +192,7 @@ def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, 
                                                 C.c_void_p(x_local.data_ptr()), C.c_void_p(out.data_ptr()), log2n_total, batch,
                                                 1 if natural_output else 0, _stream_ptr()))
         return out
+    import torch
     backend = backend or HipBackend()
     G, g = comm.size, comm.rank
     if G == 1:
@@ -192,24 +200,42 @@ def ntt_sharded(field, x_local, log2n_total, comm, inverse=False, backend=None, 
     lg = _log2(G)
     if lg > 3:
         raise ValueError("ntt_sharded supports 2, 4 or 8 ranks")
-    M = x_local.shape[0]
-    if (M << lg) != (1 << log2n_total) or M % G:
+    M = x_local.shape[0] // batch
+    if (M << lg) != (1 << log2n_total) or M % G or M * batch != x_local.shape[0]:
         raise ValueError(f"local shard of {M} elements does not match 2^{log2n_total} over {G} ranks")
     sl = M // G
     tail = tuple(x_local.shape[1:])
-    # 1. all-to-all: slice h of j2 goes to rank h  ->  [G (j1), sl, ...]
-    recv = comm.all_to_all(x_local.reshape((G, sl) + tail))
-    # 2. cross-shard step on this rank's j2 slice
-    y = backend.cross(field, recv.reshape((G * sl,) + tail), log2n_total, lg, g * sl, sl, inverse)
-    # 3. all-to-all: row k1 goes to rank k1  ->  Y[g][all j2]
-    row = comm.all_to_all(y.reshape((G, sl) + tail)).reshape((M,) + tail)
-    # 4. local M-point transform: z[k2] = X[g + G*k2]
-    z = backend.local_ntt(field, row, log2n_total - lg, inverse)
-    if not natural_output:
-        return z
-    # 5. all-to-all + local interleave: natural index g*M + (k1 + G*k2')
-    recv3 = comm.all_to_all(z.reshape((G, sl) + tail))          # [k1, k2', ...]
-    return recv3.transpose(0, 1).contiguous().reshape((M,) + tail)
+    last_step = stop_after if stop_after else (6 if natural_output else 4)
+    outs = []
+    for bi in range(batch):                 # comm.hip walks the columns diagonal by diagonal on two streams; per column the
+        col = x_local[bi * M:(bi + 1) * M]  # steps and their data are exactly these
+        # 1 (A). all-to-all: slice h of my block goes to rank h; chunk j of the receive buffer came from rank j
+        cur = comm.all_to_all(col.reshape((G, sl) + tail)).reshape((M,) + tail)
+        if last_step >= 2:   # 2 (B). cross-shard step on this rank's j2 slice [g*sl, (g+1)*sl), chunks sl apart
+            cur = backend.cross(field, cur, log2n_total, lg, g * sl, sl, inverse)
+        if last_step >= 3:   # 3 (C). all-to-all: row k1 goes to rank k1  ->  Y[g][all j2]
+            cur = comm.all_to_all(cur.reshape((G, sl) + tail)).reshape((M,) + tail)
+        if last_step >= 4:   # 4 (D). local M-point transform: z[k2] = X[g + G*k2]
+            cur = backend.local_ntt(field, cur, log2n_total - lg, inverse)
+        if last_step >= 5:   # 5 (E). all-to-all: slice h of my cyclic shard goes to rank h  ->  [k1, k2', ...]
+            cur = comm.all_to_all(cur.reshape((G, sl) + tail)).reshape((M,) + tail)
+        if last_step >= 6:   # 6 (F). local interleave: natural index g*M + (k1 + G*k2')
+            cur = cur.reshape((G, sl) + tail).transpose(0, 1).contiguous().reshape((M,) + tail)
+        outs.append(cur)
+    if stop_after:
+        return torch.stack(outs)
+    return outs[0] if batch == 1 else torch.cat(outs)
+
+
+def ntt_sharded_selftest_steps(field, x_full, log2n_total, log2_shards, stop_after, inverse=False, natural_output=True, batch=1):
+    """lw_hip_ntt_sharded_selftest_steps_device: the C++ schedule cut after step `stop_after`; block g of every batch entry
+    of the result is what virtual rank g holds at that point."""
+    import torch
+    out = torch.empty_like(x_full)
+    check(L.lib().lw_hip_ntt_sharded_selftest_steps_device(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD,
+                                                           C.c_void_p(x_full.data_ptr()), C.c_void_p(out.data_ptr()), log2n_total,
+                                                           log2_shards, batch, 1 if natural_output else 0, stop_after, _stream_ptr()))
+    return out
 
 
 # ---------------------------------------------------------------- sharded MSM

@@ -129,6 +129,9 @@ extern "C" {
     pub fn lw_hip_ntt_sharded_selftest_device(field: Field, layout: Layout, dir: Dir, d_in_full: *const c_void,
                                               d_out_full: *mut c_void, log2n_total: u32, log2_shards: u32, batch: u32,
                                               natural_output: c_int, hip_stream: *mut c_void) -> c_int;
+    pub fn lw_hip_ntt_sharded_selftest_steps_device(field: Field, layout: Layout, dir: Dir, d_in_full: *const c_void,
+                                                    d_out_full: *mut c_void, log2n_total: u32, log2_shards: u32, batch: u32,
+                                                    natural_output: c_int, stop_after: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn lw_hip_msm_sharded_device(curve: Curve, d_scalars: *const u64, d_points: *const c_void, n_local: usize,
                                      out_point_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
 

@@ -48,6 +48,17 @@ def _worker(rank, world, port, q):
             ok &= np.array_equal(cyc.numpy().view(mine.dtype).reshape(mine.shape), exp[rank::world])
             back = D.ntt_sharded(fld, out, L, comm, inverse=True, backend=be)
             ok &= np.array_equal(back.numpy().view(mine.dtype).reshape(mine.shape), mine)
+        # a batch of two columns through the same per-column steps (BASELINE config 4 has four)
+        name, fld = "babybear_u32", fft.Babybear31PrimeFieldU32
+        oid = util.field_pairs()[name][1]
+        L, B = 5, 2
+        n, M = 1 << L, (1 << L) // world
+        cols = [util.rand_elems(name, n, 200 + c) for c in range(B)]
+        mine = np.concatenate([c[rank * M:(rank + 1) * M] for c in cols])
+        got = D.ntt_sharded(fld, torch.from_numpy(mine.view(np.int32)), L, comm, backend=OracleBackend(oid), batch=B).numpy().view(np.uint32)
+        for c in range(B):
+            exp = np.asarray(O.fft(oid, cols[c], O.get_twiddles(oid, L, O.ROOTS_BITREV))).reshape(-1)
+            ok &= np.array_equal(got[c * M:(c + 1) * M], exp[rank * M:(rank + 1) * M])
         # MSM: shard by points, all-gather the partial sums
         oid = O.C_BN254_G1
         scalars, points = util.msm_case(oid, 12, 5)

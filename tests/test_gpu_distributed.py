@@ -103,6 +103,57 @@ def test_library_sharded_schedule_selftest_matches_oracle(name, lg, L):
     assert np.array_equal(view(back), full)
 
 
+@pytest.mark.parametrize("name,lg,L,batch", [("stark252", 1, 8, 1), ("babybear_u32", 2, 10, 3), ("fr381", 3, 9, 2), ("babybear_ext4", 2, 8, 2)])
+@pytest.mark.parametrize("natural", [True, False])
+def test_python_schedule_is_the_cpp_schedule_step_by_step(name, lg, L, batch, natural):
+    """One schedule, two spellings: csrc/comm.hip ntt_sharded_run (what RCCL runs) and distributed.ntt_sharded (what the
+    world-size-2 gloo test drives).  After EVERY step (exchange A, cross step, exchange C, local NTT, exchange E,
+    interleave) every virtual rank's buffer must hold the same bytes in both, for every batch column — chunk order of the
+    exchanges and the (j2_begin, slice_len) arguments included."""
+    from lambda_elliptic_curves_amd import distributed as D
+    fld, oid = util.field_pairs()[name]
+    n, G = 1 << L, 1 << lg
+    M = n // G
+    full = util.rand_elems(name, batch * n, 940 + L)
+    t_full = _as_t(full)
+    comms = D.SimComm.make(G)
+    for step in range(1, (6 if natural else 4) + 1):
+        cpp = D.ntt_sharded_selftest_steps(fld, t_full, L, lg, step, natural_output=natural, batch=batch)
+        torch.cuda.synchronize()
+        cpp = cpp.cpu().numpy().view(full.dtype).reshape((batch, G, M) + full.shape[1:])
+
+        def rank(r):
+            mine = np.concatenate([full[bi * n + r * M: bi * n + (r + 1) * M] for bi in range(batch)])
+            out = D.ntt_sharded(fld, _as_t(mine), L, comms[r], natural_output=natural, batch=batch, stop_after=step)
+            torch.cuda.synchronize()
+            return out.cpu().numpy().view(full.dtype).reshape((batch, M) + full.shape[1:])
+
+        outs = _run_ranks(G, rank)
+        for r in range(G):
+            assert np.array_equal(outs[r], cpp[:, r]), f"step {step}, rank {r}"
+
+
+@pytest.mark.parametrize("natural", [True, False])
+def test_library_sharded_schedule_batched_and_cyclic(natural):
+    # batch > 1 with the cyclic output: step D must not read one batch entry with the other's stride (ADVICE r2)
+    from lambda_elliptic_curves_amd import distributed as D
+    fld, oid = util.field_pairs()["babybear_u64"]
+    L, lg, B = 12, 2, 4
+    n, G = 1 << L, 1 << lg
+    M = n // G
+    full = util.rand_elems("babybear_u64", B * n, 77)
+    got = D.ntt_sharded_selftest(fld, _as_t(full), L, lg, natural_output=natural, batch=B)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().view(np.uint64).reshape(B, n)
+    for bi in range(B):
+        exp = np.asarray(O.evaluate_fft(oid, full[bi * n:(bi + 1) * n])).reshape(-1)
+        if natural:
+            assert np.array_equal(got[bi], exp)
+        else:
+            for g in range(G):
+                assert np.array_equal(got[bi, g * M:(g + 1) * M], exp[g::G])
+
+
 def test_library_sharded_schedule_selftest_config4_shape():
     # BASELINE config 4: 4 BabyBear columns x 2^24 over 8 ranks (2^21 elements per rank and column), one batched call;
     # every column equals the single-device transform, which test_gpu_parity_full pins to the oracle at this size

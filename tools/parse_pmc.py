@@ -9,7 +9,9 @@ lines + 1.07 GB of indices) and its raw FETCH_SIZE read 35.5 GB when this was ca
 dispatch; c = 20: 218 M items, 28.8 GB expected, 32.6-33.8 GB read), i.e. the counter is within 15 % of the line count for
 whole-line gathers and nowhere near half of it — so kernels whose name contains "msm_accumulate" take factor 1, everything
 else factor 2.
-usage: parse_pmc.py FETCH_DIR WRITE_DIR NTT_LOG2N MSM_LOG2N MSM_STEPS_TIMED OUT.json"""
+With the two bench lines (plain run, run under rocprofv3 --kernel-trace --stats) it also records how much slower the
+kernels ran under the profiler, so that profiles/*kernel_stats.csv can be compared with the unprofiled bench line.
+usage: parse_pmc.py FETCH_DIR WRITE_DIR NTT_LOG2N MSM_LOG2N MSM_STEPS_TIMED OUT.json [BENCH.json BENCH_UNDER_ROCPROF.json]"""
 import csv
 import glob
 import json
@@ -43,10 +45,26 @@ def main():
     msm = {k: v for k, v in rows.items() if "lw::msm_" in k}
     msm_total = sum(v["hbm_bytes"] * v["launches"] for v in msm.values())
     n_msm = 2 + msm_steps
+    ratio = None
+    if len(sys.argv) > 8:
+        try:
+            plain, prof = (json.loads(open(p).read().strip().splitlines()[-1]) for p in (sys.argv[7], sys.argv[8]))
+            ratio = {"ntt_ms_per_step": {"plain": plain["ms_per_step"], "under_rocprofv3": prof["ms_per_step"],
+                                         "ratio": prof["ms_per_step"] / plain["ms_per_step"]},
+                     "ntt_pass_avg_launch_ms": {"plain": plain["roofline"]["avg_launch_ms"], "under_rocprofv3": prof["roofline"]["avg_launch_ms"],
+                                                "ratio": prof["roofline"]["avg_launch_ms"] / plain["roofline"]["avg_launch_ms"]},
+                     "msm_ms_per_step": {"plain": plain["msm"]["ms_per_step"], "under_rocprofv3": prof["msm"]["ms_per_step"],
+                                         "ratio": prof["msm"]["ms_per_step"] / plain["msm"]["ms_per_step"]},
+                     "what": "the same bench.py command with and without rocprofv3 --kernel-trace --stats in one gpurun call: kernels "
+                             "run slower under the profiler, so kernel_stats.csv averages are compared with the line printed inside "
+                             "the profiled process (bench_under_rocprof.json), not with the plain one"}
+        except Exception as e:   # noqa: BLE001
+            ratio = {"error": str(e)[:200]}
     src = "profiles/traffic_latest.json (tools/profile_all.sh, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py)"
     json.dump({"ntt": {"log2n": ntt_log2n, "hbm_bytes_per_launch": per_launch, "source": src},
                "msm": {"log2n": msm_log2n, "hbm_bytes_per_launch": msm_total / n_msm, "msms_in_profile": n_msm, "source": src,
                        "what": "HBM bytes of all MSM kernels of one MSM (sum over kernels of mean bytes x launches / MSMs run)"},
+               "profiled_vs_unprofiled": ratio,
                "kernels": rows,
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs; KiB units; FETCH_SIZE doubled (gfx950 streaming reads) except for the whole-line gathers of msm_accumulate_kernel, calibrated at factor 1 on their known line count"},
               open(out, "w"), indent=1)
