@@ -92,7 +92,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=24, help="NTT size (Stark252)")
     ap.add_argument("--msm-log2n", type=int, default=24, help="MSM size (BLS12-381 G1)")
-    ap.add_argument("--workload", choices=["ntt", "msm", "all"], default="all")
+    ap.add_argument("--workload", choices=["ntt", "msm", "all", "cfg4", "cfg5"], default="all",
+                    help="all = the headline (BASELINE configs 2 + 3); cfg4 / cfg5 = BASELINE's multi-GPU configurations (bench_cfg.py), "
+                         "runnable at any --gpus N (N = 1: through the library's 1-rank communicator)")
+    ap.add_argument("--cfg5-log2n", type=int, default=26, help="total points of --workload cfg5")
     ap.add_argument("--dist-mode", choices=["sharded", "independent"], default="sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (and with them the bit-exact checks)")
     ap.add_argument("--no-host-path", action="store_true")
@@ -161,6 +164,28 @@ def main():
 
     result = {}
     mismatch = []
+    # ------------------------------------------------------------------ BASELINE configs 4 and 5 (bench_cfg.py)
+    if args.workload in ("cfg4", "cfg5"):
+        import bench_cfg
+
+        def comm_factory():
+            if comm is not None or world > 1:
+                return comm, comm_error
+            try:   # N = 1: a 1-rank communicator, so that the sharded entry points (and RCCL) are what is timed
+                return D.HipComm(D.HipComm.unique_id(), 0, 1), None
+            except Exception as e:
+                return None, "%s: %s" % (type(e).__name__, str(e)[:160])
+        fn = bench_cfg.run_cfg4 if args.workload == "cfg4" else bench_cfg.run_cfg5
+        result, ok = fn(args, world, rank, barrier, max_over_ranks, all_ranks_ok, comm_factory)
+        comm = None   # closed by the leg
+        if rank == 0:
+            print(json.dumps(result))
+        if world > 1:
+            dist.destroy_process_group()
+        if not ok:
+            print("bench.py: BIT-EXACTNESS FAILURE in %s" % args.workload, file=sys.stderr)
+            sys.exit(1)
+        return
     # ------------------------------------------------------------------ NTT leg
     if args.workload in ("ntt", "all"):
         L = args.log2n
@@ -280,6 +305,12 @@ def main():
             for _ in range(2):
                 fft.ntt(fld, host)          # a fresh result buffer per call, as Polynomial::evaluate_fft returns a new Vec
             dth = (time.perf_counter() - t0) / 2
+            keep = [fft.ntt(fld, host)]
+            t0 = time.perf_counter()
+            for _ in range(2):
+                keep.append(fft.ntt(fld, host))   # fresh result buffers again, but alive past the loop: the call alone, without the free
+            dtk = (time.perf_counter() - t0) / 2
+            del keep
             out_h = np.empty_like(host)
             args_h = (fld.field, fld.layout, _lib.DIR_FORWARD, host.ctypes.data_as(C.c_void_p), out_h.ctypes.data_as(C.c_void_p), L, 1, 0, None)
             _lib.lib().lw_hip_ntt(*args_h)
@@ -287,10 +318,24 @@ def main():
             for _ in range(3):
                 _lib.lib().lw_hip_ntt(*args_h)   # caller-owned buffers reused across calls
             dtr = (time.perf_counter() - t0) / 3
-            hp["ntt"] = {"ms": dth * 1e3, "elements_per_s": n / dth, "ms_reused_buffers": dtr * 1e3,
+            # the result in a pinned buffer of the library's pool (lw_hip_result_acquire): a new buffer object per call, as a
+            # Vec-shaped result is, but recycled resident memory underneath
+            with fft.ResultBuffer(fld, n) as rb:
+                fft.ntt(fld, host, out=rb.array)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                with fft.ResultBuffer(fld, n) as rb:
+                    fft.ntt(fld, host, out=rb.array)
+            dtp = (time.perf_counter() - t0) / 3
+            hp["ntt"] = {"ms": dth * 1e3, "elements_per_s": n / dth, "ms_fresh_result_call_only": dtk * 1e3, "ms_reused_buffers": dtr * 1e3,
+                         "ms_pooled_result": dtp * 1e3,
                          "what": "lw_hip_ntt on host buffers, Stark252 2^%d: H2D + transform + D2H (%d MiB each way); 'ms' = new "
-                                 "result buffer per call (populated by the library while the upload and kernels run), "
-                                 "'ms_reused_buffers' = same buffers every call" % (L, n * 32 >> 20)}
+                                 "numpy result buffer per call (huge pages requested, populated by helper threads while the upload "
+                                 "and kernels run, downloaded chunk by chunk behind the populate front; includes freeing the "
+                                 "previous result: munmap of 512 MiB alone is 19-39 ms on this host, profiles/r03_thp_populate.txt), "
+                                 "'ms_fresh_result_call_only' = the same with the results kept alive (no free inside the loop), "
+                                 "'ms_reused_buffers' = same caller buffers every call, 'ms_pooled_result' = result "
+                                 "in a pinned buffer acquired from / released to the library's pool per call" % (L, n * 32 >> 20)}
             result["host_path"] = hp
         del t_in, t_out, host, last
         torch.cuda.empty_cache()

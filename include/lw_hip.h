@@ -124,6 +124,16 @@ int lw_hip_profile_end(lw_profile_t *out);  /* synchronise, stop, report */
 size_t lw_hip_field_elem_bytes(lw_field_t field, lw_layout_t layout);
 size_t lw_hip_curve_point_bytes(lw_curve_t curve);
 
+/* Result buffers for the host-buffer entry points.  Polynomial::evaluate_fft returns a NEW Vec on every call
+ * (math/src/fft/polynomial.rs:37-38, fft/gpu/cuda/state.rs:61-68,197-202): a 512 MiB result that has never been touched costs
+ * 131072 first-touch page faults when the device-to-host copy lands in it — several times the copy itself.  A caller that
+ * can hold its result in a library buffer asks for one here: pinned, resident memory from a small pool (reused across
+ * calls, released with lw_hip_result_release or at lw_hip_shutdown), into which lw_hip_ntt / lw_polynomial_evaluate_fft
+ * copy at the PCIe rate.  Any other `out` pointer keeps working: large fresh buffers are populated (huge pages where the
+ * host grants them) by helper threads while the upload and the kernels run, and downloaded chunk by chunk behind that. */
+int lw_hip_result_acquire(size_t bytes, void **out_ptr);
+int lw_hip_result_release(void *ptr);
+
 /* ---- NTT backend seam ----
  * `in` holds `batch` transforms of 2^log2n elements, `batch_stride_elems` apart (0 -> dense).  Forward:
  * natural-order coefficients -> natural-order evaluations at w^i.  Inverse: evaluations -> coefficients,

@@ -19,7 +19,7 @@ CURVE_BLS12_381_G1, CURVE_BN254_G1, CURVE_BN254_G2, CURVE_BLS12_381_G2 = 0, 1, 2
 
 EXPORTS = [
     "lw_hip_init", "lw_hip_shutdown", "lw_hip_device_count", "lw_hip_last_error", "lw_hip_get_timings",
-    "lw_hip_profile_begin", "lw_hip_profile_end",
+    "lw_hip_profile_begin", "lw_hip_profile_end", "lw_hip_result_acquire", "lw_hip_result_release",
     "lw_hip_field_elem_bytes", "lw_hip_curve_point_bytes", "lw_hip_ntt", "lw_hip_ntt_device", "lw_hip_ntt_cross_device",
     "lw_hip_gen_twiddles", "lw_hip_gen_powers", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
@@ -77,6 +77,10 @@ def lib():
     L.lw_hip_profile_begin.restype = i
     L.lw_hip_profile_end.argtypes = [C.POINTER(Profile)]
     L.lw_hip_profile_end.restype = i
+    L.lw_hip_result_acquire.argtypes = [sz, C.POINTER(vp)]
+    L.lw_hip_result_acquire.restype = i
+    L.lw_hip_result_release.argtypes = [vp]
+    L.lw_hip_result_release.restype = i
     L.lw_hip_field_elem_bytes.argtypes = [i, i]
     L.lw_hip_field_elem_bytes.restype = sz
     L.lw_hip_curve_point_bytes.argtypes = [i]

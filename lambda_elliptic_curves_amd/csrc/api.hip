@@ -4,6 +4,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -123,8 +124,10 @@ static int init_locked(Context &c, const int *device_ids, int n_devices) {
 
 void comm_release(Context &c);   // comm.hip
 
+void host_pool_release_all();
 void Context::release_all() {
     (void)hipDeviceSynchronize();
+    host_pool_release_all();
     comm_release(*this);
     for (int f = 0; f < 3; f++)
         for (int d = 0; d < 2; d++) {
@@ -139,6 +142,7 @@ void Context::release_all() {
         coset[i].valid = false;
     }
     msm_ws.release();
+    if (pinned_words) { (void)hipHostFree(pinned_words); pinned_words = nullptr; }
     msm_scalars.release();
     msm_affine.release();
     msm_prefix.release();
@@ -315,34 +319,90 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
     return ntt256_device(c, (int)field, dir, d_in, d_out, log2n, batch, stride, coset ? cw : nullptr, stream, in_log2);
 }
 
+// ---- pinned result buffers (lw_hip_result_acquire / release) ----
+// hipHostMalloc'ed, i.e. resident and DMA-able: a device-to-host copy into one runs at the PCIe rate with no page fault.
+// Released buffers are kept (up to 4) and handed out again to requests they fit within a factor of two.
+struct HostPool {
+    struct Buf { void *p; size_t bytes; bool in_use; };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+};
+static HostPool g_host_pool;
+bool host_pool_owns(const void *p) {
+    std::lock_guard<std::mutex> g(g_host_pool.mu);
+    for (auto &b : g_host_pool.bufs)
+        if ((const char *)p >= (const char *)b.p && (const char *)p < (const char *)b.p + b.bytes) return true;
+    return false;
+}
+void host_pool_release_all() {
+    std::lock_guard<std::mutex> g(g_host_pool.mu);
+    for (auto &b : g_host_pool.bufs) (void)hipHostFree(b.p);
+    g_host_pool.bufs.clear();
+}
+
 // A fresh result buffer (a Rust `Vec::with_capacity`, numpy's `empty`) has never been touched: the device-to-host copy
-// into it then runs at the kernel's single-threaded page-fault rate (512 MiB: ~60 ms) instead of the PCIe rate (~9 ms).
-// The host-buffer entry points therefore populate large outputs with a few threads WHILE the upload and the kernels
-// run; MADV_POPULATE_WRITE maps the pages without changing their contents.  Joined before the copy back.
+// into it then runs at the kernel's page-fault rate (512 MiB = 131072 first-touch faults: 35-45 ms) instead of the PCIe rate
+// (~9 ms).  The host-buffer entry points therefore (a) ask for transparent huge pages on the 2 MiB-aligned interior of a
+// large output (madvise MADV_HUGEPAGE: 256 faults instead of 131072 where the host allows it, LW_HIP_HOST_THP=0 skips it),
+// (b) populate it with a few threads, chunk by chunk in address order, WHILE the upload and the kernels run
+// (MADV_POPULATE_WRITE maps the pages without changing their contents), and (c) copy each chunk back as soon as it is
+// mapped, so the download runs behind the populate front instead of after it.  Callers that can hold results in a
+// library buffer skip all of this: lw_hip_result_acquire hands out pinned, resident memory.
 struct Prefault {
+    static constexpr size_t CHUNK = (size_t)32 << 20;
     std::vector<std::thread> th;
-    void start(void *p, size_t bytes, const void *in, size_t in_bytes) {
+    std::vector<std::atomic<int>> done;
+    char *base = nullptr;
+    size_t bytes = 0, nchunks = 0;
+    bool active = false;
+    void start(void *p, size_t nbytes, const void *in, size_t in_bytes) {
         const uintptr_t a = (uintptr_t)p, b = (uintptr_t)in;
-        if (bytes < ((size_t)32 << 20) || (a < b + in_bytes && b < a + bytes)) return;   // small, or aliases the input (already mapped)
+        base = (char *)p;
+        bytes = nbytes;
+        if (nbytes < ((size_t)32 << 20) || (a < b + in_bytes && b < a + nbytes) || host_pool_owns(p)) return;   // small, aliases the input (already mapped), or pinned
         const size_t page = (size_t)sysconf(_SC_PAGESIZE);
-        const uintptr_t lo = (a + page - 1) & ~(uintptr_t)(page - 1), hi = (a + bytes) & ~(uintptr_t)(page - 1);
-        if (hi <= lo) return;
+#ifdef MADV_HUGEPAGE
+        static const bool thp = [] { const char *e = tuning_env("LW_HIP_HOST_THP"); return !e || atoi(e) != 0; }();
+        if (thp) {
+            const uintptr_t H = (uintptr_t)2 << 20, hlo = (a + H - 1) & ~(H - 1), hhi = (a + nbytes) & ~(H - 1);
+            if (hhi > hlo) (void)madvise((void *)hlo, hhi - hlo, MADV_HUGEPAGE);   // best effort
+        }
+#endif
+        nchunks = (nbytes + CHUNK - 1) / CHUNK;
+        done = std::vector<std::atomic<int>>(nchunks);
+        for (auto &d : done) d.store(0, std::memory_order_relaxed);
         unsigned T = std::thread::hardware_concurrency();
         T = T < 2 ? 1 : (T > 8 ? 8 : T);
-        const size_t pages = (hi - lo) / page, per = (pages + T - 1) / T;
+        active = true;
         for (unsigned t = 0; t < T; t++) {
-            const size_t p0 = (size_t)t * per, p1 = p0 + per < pages ? p0 + per : pages;
-            if (p0 >= p1) break;
             try {   // nothing may propagate across the C ABI: without a helper thread the copy simply faults the pages itself
-                th.emplace_back([=] {
+                th.emplace_back([this, t, T, page, a] {
+                    for (size_t k = t; k < nchunks; k += T) {
+                        const uintptr_t c0 = a + k * CHUNK, c1 = c0 + CHUNK < a + bytes ? c0 + CHUNK : a + bytes;
+                        const uintptr_t lo = (c0 + page - 1) & ~(uintptr_t)(page - 1), hi = c1 & ~(uintptr_t)(page - 1);
 #ifdef MADV_POPULATE_WRITE
-                    (void)madvise((void *)(lo + p0 * page), (p1 - p0) * page, MADV_POPULATE_WRITE);   // best effort
+                        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_POPULATE_WRITE);   // best effort
 #endif
+                        done[k].store(1, std::memory_order_release);
+                    }
                 });
             } catch (...) {
-                break;
+                for (size_t k = t; k < nchunks; k += T) done[k].store(1, std::memory_order_release);   // nobody will populate these
             }
         }
+    }
+    // dst = base + off: device -> host, chunk by chunk behind the populate front (one plain copy when nothing is being populated)
+    int copy_back(const void *d_src, size_t nbytes) {
+        if (!active) {
+            LW_HIP_CHECK(hipMemcpy(base, d_src, nbytes, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+            return LW_OK;
+        }
+        for (size_t k = 0; k < nchunks; k++) {
+            while (!done[k].load(std::memory_order_acquire)) std::this_thread::yield();
+            const size_t off = k * CHUNK, len = off + CHUNK < nbytes ? CHUNK : nbytes - off;
+            LW_HIP_CHECK(hipMemcpy(base + off, (const char *)d_src + off, len, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+        }
+        return LW_OK;
     }
     void join() {
         for (auto &t : th) t.join();
@@ -454,6 +514,48 @@ size_t lw_hip_curve_point_bytes(lw_curve_t curve) {
         case LW_CURVE_BLS12_381_G2: return 288;
         default: return 0;
     }
+}
+
+int lw_hip_result_acquire(size_t bytes, void **out_ptr) {
+    if (!out_ptr || bytes == 0) { set_error("null or empty request"); return LW_ERR_BAD_ARG; }
+    Entry en(nullptr);   // binds the context's device: pinned memory is registered with it
+    if (en.rc) return en.rc;
+    {
+        std::lock_guard<std::mutex> g(g_host_pool.mu);
+        HostPool::Buf *best = nullptr;
+        for (auto &b : g_host_pool.bufs)
+            if (!b.in_use && b.bytes >= bytes && b.bytes / 2 <= bytes && (!best || b.bytes < best->bytes)) best = &b;
+        if (best) { best->in_use = true; *out_ptr = best->p; return LW_OK; }
+    }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return LW_ERR_ALLOC; }
+    std::lock_guard<std::mutex> g(g_host_pool.mu);
+    g_host_pool.bufs.push_back(HostPool::Buf{p, bytes, true});
+    *out_ptr = p;
+    return LW_OK;
+}
+
+int lw_hip_result_release(void *ptr) {
+    if (!ptr) return LW_OK;
+    void *to_free = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_host_pool.mu);
+        size_t idle = 0;
+        HostPool::Buf *mine = nullptr;
+        for (auto &b : g_host_pool.bufs) {
+            if (b.p == ptr) mine = &b;
+            else if (!b.in_use) idle++;
+        }
+        if (!mine || !mine->in_use) { set_error("pointer was not handed out by lw_hip_result_acquire"); return LW_ERR_BAD_ARG; }
+        mine->in_use = false;
+        if (idle >= 4) {   // keep at most four idle buffers
+            to_free = mine->p;
+            g_host_pool.bufs.erase(g_host_pool.bufs.begin() + (mine - g_host_pool.bufs.data()));
+        }
+    }
+    if (to_free) (void)hipHostFree(to_free);
+    return LW_OK;
 }
 
 int lw_hip_ntt_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out, uint32_t log2n,
@@ -607,11 +709,12 @@ int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *i
     LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, in, span, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     rc = ntt_device_locked(c, field, layout, dir, c.host_io_a.p, c.host_io_b.p, log2n, batch, stride, coset_offset_or_null, 0);
     if (rc) return rc;
-    pf.join();
     LW_HIP_CHECK(hipStreamSynchronize(0), LW_ERR_LAUNCH);
     if (stride == n) {
-        LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, span, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+        rc = pf.copy_back(c.host_io_b.p, span);
+        if (rc) return rc;
     } else {   // leave the gaps between strided transforms untouched
+        pf.join();
         LW_HIP_CHECK(hipMemcpy2D(out, stride * eb, c.host_io_b.p, stride * eb, n * eb, batch, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
     }
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -675,8 +778,9 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
     rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, 0,
                            lde ? in_log2 : log2n);
     if (rc) return rc;
-    pf.join();
-    LW_HIP_CHECK(hipMemcpy(out, c.host_io_b.p, len * eb, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(0), LW_ERR_LAUNCH);
+    rc = pf.copy_back(c.host_io_b.p, len * eb);
+    if (rc) return rc;
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.ntt_calls++;
     return LW_OK;

@@ -459,34 +459,38 @@ int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     Context &c = en.c;
     const int G = g_comm.nranks;
-    // payload per rank: [status (8 bytes) | partial sum].  The local MSM runs first and its outcome travels WITH the point:
+    // payload per rank: [status (16-byte header, so that the point keeps the 16-byte alignment its stores assume) | partial sum].  The local MSM runs first and its outcome travels WITH the point:
     // a rank whose MSM failed still enters the all-gather (status != 0, identity payload), so nobody is left blocked in the
     // collective, and every rank returns LW_ERR_COMM together.
-    const size_t slot = 8 + pb;
-    std::vector<char> mine(slot, 0), all(slot * G);
-    const int local_rc = msm_device(c, curve, d_scalars, d_points, n_local, mine.data() + 8, en.stream, 0, 0);
+    constexpr size_t HDR = 16;
+    const size_t slot = HDR + pb;
+    std::vector<uint4> mine_v((slot + 15) / 16), all_v((slot * G + 15) / 16);   // 16-byte aligned host staging
+    char *mine = (char *)mine_v.data(), *all = (char *)all_v.data();
+    memset(mine, 0, slot);
+    const int local_rc = msm_device(c, curve, d_scalars, d_points, n_local, mine + HDR, en.stream, 0, 0);
     const int64_t st = local_rc;
-    memcpy(mine.data(), &st, 8);
-    if (local_rc) memset(mine.data() + 8, 0, pb);
+    memcpy(mine, &st, 8);
+    if (local_rc) memset(mine + HDR, 0, pb);
     if (c.shard_a.ensure(slot * (G + 1))) {
         // cannot even stage 152 bytes: nothing to send — the peers will time out in RCCL; report it
         return LW_ERR_ALLOC;
     }
     char *d_send = (char *)c.shard_a.p, *d_recv = d_send + slot;
-    LW_HIP_CHECK(hipMemcpyAsync(d_send, mine.data(), slot, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpyAsync(d_send, mine, slot, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
     LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, slot, ncclChar, g_comm.comm, en.stream));
-    LW_HIP_CHECK(hipMemcpyAsync(all.data(), d_recv, slot * G, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpyAsync(all, d_recv, slot * G, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
     LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
     if (local_rc) return local_rc;
-    std::vector<char> pts(pb * G);
+    std::vector<uint4> pts_v((pb * G + 15) / 16);
+    char *pts = (char *)pts_v.data();
     for (int g = 0; g < G; g++) {
         int64_t sg = 0;
-        memcpy(&sg, all.data() + slot * g, 8);
+        memcpy(&sg, all + slot * g, 8);
         if (sg) { set_error("rank %d failed its local MSM (status %lld)", g, (long long)sg); return LW_ERR_COMM; }
-        memcpy(pts.data() + pb * g, all.data() + slot * g + 8, pb);
+        memcpy(pts + pb * g, all + slot * g + HDR, pb);
     }
     // <= 7 group additions on the host (same limb code as the device)
-    return msm_sum_points_host(curve, pts.data(), (size_t)G, out_point_host);
+    return msm_sum_points_host(curve, pts, (size_t)G, out_point_host);
 }
 
 }  // extern "C"

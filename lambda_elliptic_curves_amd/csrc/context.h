@@ -81,6 +81,7 @@ struct Context {
     DeviceBuf small;         // staging for small power tables
     CosetCache coset[3];     // forward coset, inverse coset, multi-GPU cross-step twiddle base
     DeviceBuf msm_ws;
+    uint32_t *pinned_words = nullptr;   // 64 pinned host words: small device -> host results read while other streams run (msm_core.cuh)
     DeviceBuf msm_scalars;   // canonical scalars when the caller hands Montgomery-form FrElements
     // set by the SRS entry points around msm_device, under the entry lock: the point set holds window-shifted copies
     // (rows w * stride + i = 2^(c w) P_i) and all windows share one bucket set (msm_core.cuh build_fold)

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const ui
 }
 template <class ITEM>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
-                                                                 uint64_t idx_stride, uint32_t folded, const uint32_t *coarse_off,
+                                                                 uint64_t idx_stride, uint32_t folded, uint32_t win0, const uint32_t *coarse_off,
                                                                  uint32_t *coarse_cursor, ItemMem<ITEM> items) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];   // + dummy slot for zero digits
     __shared__ uint32_t base[SORT_MAX_COARSE];    // next free slot of this workgroup's run per bin
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
     __shared__ uint16_t bbin[COARSE_CHUNK];       // bin of every staged item
     const uint32_t NB = 1u << hb, w = blockIdx.y, tid = threadIdx.x;
     const uint32_t bin0 = folded ? 0u : (w << hb);   // folded: every window sorts into the one shared bucket set
-    const uint64_t idx0 = (uint64_t)w * idx_stride;      // and its items point at the window's own copy of the points
+    const uint64_t idx0 = (uint64_t)(win0 + w) * idx_stride;   // and its items point at the window's own copy of the points
     for (uint32_t b = tid; b <= SORT_MAX_COARSE; b += SORT_THREADS) h[b] = 0;
     __syncthreads();
     const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
@@ -610,26 +610,31 @@ uint32_t msm_max_window_bits() { return MSM_MAX_C; }
 // row length of the digit matrix: a multiple of 8 (uint4 loads) that is not a power of two, so that the W rows a wave
 // writes do not all fall on the same memory channel
 uint64_t msm_sort_padded_points(uint64_t n) { return ((n + 7) & ~(uint64_t)7) + 1032; }
-template <class ITEM>
-static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, const SortSplit &sp, uint32_t CB,
-                          uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ItemMem<ITEM> items,
-                          uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
-                          uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride, hipStream_t s) {
+// level 0: the W x n_pad digit matrix of all windows (shared by the window slices of msm_core.cuh run())
+void msm_launch_digits(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, hipStream_t s) {
     const uint64_t n_pad = msm_sort_padded_points(n);
-    const uint32_t folded = fold_stride != 0;
-    const uint32_t fine = sp.fine, hb = sp.hb;
     hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n_pad + 256 * DIGITS_PER_THREAD - 1) / (256 * DIGITS_PER_THREAD))), dim3(256), 0, s,
                        scalars, n, n_pad, cb, W, dig);
     c.prof_end("msm_digits_kernel", pe, s);
+}
+// `dig`: row 0 = the first of the W windows sorted here (a slice of the matrix); win0: that window's number in the MSM
+template <class ITEM>
+static void launch_sort_t(Context &c, uint64_t n, uint32_t cb, uint32_t W, const SortSplit &sp, uint32_t CB,
+                          const uint32_t *dig, uint32_t *coarse_cnt, uint32_t *coarse_off, uint32_t *coarse_cursor, ItemMem<ITEM> items,
+                          uint32_t *sorted, uint32_t *off, uint32_t K, uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off,
+                          uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride, uint32_t win0, hipStream_t s) {
+    const uint64_t n_pad = msm_sort_padded_points(n);
+    const uint32_t folded = fold_stride != 0;
+    const uint32_t fine = sp.fine, hb = sp.hb;
     const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
-    pe = c.prof_begin(s);
+    hipEvent_t pe = c.prof_begin(s);
     hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, folded, coarse_cnt);
     c.prof_end("msm_coarse_kernel<count>", pe, s);
     msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
     pe = c.prof_begin(s);
     hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, fold_stride, folded,
-                       (const uint32_t *)coarse_off, coarse_cursor, items);
+                       win0, (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
     // level B: sub-blocks of the coarse bins -> key counts -> key offsets (+ the longest bucket) -> sorted index list
     msm_launch_scan(coarse_off, sub_off, CB, (int)FINE_SUB, maxlen + 1, scan_tmp, s);
@@ -644,23 +649,23 @@ static void launch_sort_t(Context &c, const uint32_t *scalars, uint64_t n, uint3
                        (const uint32_t *)sub_off, CB, fine, (const uint32_t *)off, key_cursor, sorted);
     c.prof_end("msm_fine_kernel", pe, s);
 }
-// dig: W * padded(n) u32; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off, sub_off: CB + 1; items: n*W u64;
+// dig: W rows of padded(n) u32; coarse_cnt / coarse_cursor: CB + 1 zeroed u32 each; coarse_off, sub_off: CB + 1; items: n*W u64;
 // key_cnt / key_cursor: K zeroed u32 each; off: K + 1; maxlen: zeroed.  K = W << (cb - 1).
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
+void msm_launch_sort(Context &c, const uint32_t *dig, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride,
-                     hipStream_t s) {
+                     uint64_t win0, hipStream_t s) {
     // fold_stride != 0 (lw_hip_srs_* with window-shifted copies of the points): one bucket set of 2^(cb-1) keys for all W
     // windows; the item of window w and scalar i points at row w * fold_stride + i
     const SortSplit sp = sort_split(cb, fold_stride ? (uint64_t)W * fold_stride : n);
     const uint32_t CB = (fold_stride ? 1u : W) << sp.hb;
     if (!sp.wide)
-        launch_sort_t<uint32_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, ItemMem<uint32_t>{(uint32_t *)items},
-                                sorted, off, K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
+        launch_sort_t<uint32_t>(c, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor, ItemMem<uint32_t>{(uint32_t *)items},
+                                sorted, off, K, maxlen, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, (uint32_t)win0, s);
     else   // the 8 * n * W bytes of `items` hold n * W entries followed by n * W fine keys
-        launch_sort_t<uint64_t>(c, scalars, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor,
+        launch_sort_t<uint64_t>(c, n, cb, W, sp, CB, dig, coarse_cnt, coarse_off, coarse_cursor,
                                 ItemMem<uint64_t>{(uint32_t *)items, (uint16_t *)((uint32_t *)items + n * W)}, sorted, off, K, maxlen,
-                                scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, s);
+                                scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, (uint32_t)win0, s);
 }
 // scratch: 2 * ceil(K / SCAN_TILE) u32 (block sums, block maxima)
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s) {

@@ -18,10 +18,12 @@ constexpr int MSM_THREADS = 128;
 uint32_t msm_sort_coarse_bins(uint32_t c, uint32_t W, uint64_t n);
 uint32_t msm_max_window_bits();
 uint64_t msm_sort_padded_points(uint64_t n);
-void msm_launch_sort(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, uint32_t *coarse_cnt,
+void msm_launch_digits(Context &c, const uint32_t *scalars, uint64_t n, uint32_t cb, uint32_t W, uint32_t *dig, hipStream_t s);
+void msm_launch_sort(Context &c, const uint32_t *dig, uint64_t n, uint32_t cb, uint32_t W, uint32_t *coarse_cnt,
                      uint32_t *coarse_off, uint32_t *coarse_cursor, uint64_t *items, uint32_t *sorted, uint32_t *off, uint32_t K,
                      uint32_t *maxlen, uint32_t *scan_tmp, uint32_t *sub_off, uint32_t *key_cnt, uint32_t *key_cursor, uint64_t fold_stride,
-                     hipStream_t s);
+                     uint64_t win0, hipStream_t s);
+int ensure_aux_stream(Context &c);   // msm.hip: the context's side stream
 void msm_launch_scan(const uint32_t *in, uint32_t *out, uint32_t K, int mode, uint32_t *maxlen, uint32_t *scratch, hipStream_t s);
 size_t msm_scan_scratch_bytes(uint32_t K);
 void msm_launch_piece_order(Context &c, const uint32_t *seg_off, const uint32_t *out_off, uint32_t K, uint32_t P, uint32_t *order_tmp,
@@ -360,7 +362,7 @@ struct MsmRunner {
 
     // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
     static constexpr size_t PB = 3 * C::B::BYTES;
-    int reduce(const char *in, uint32_t n, uint32_t nwin, Carver &cv, char **S_out, char **A_out) {
+    int reduce(const char *in, uint32_t n, uint32_t nwin, Carver &cv, char **S_out, char **A_out, hipStream_t stream) {
         const uint32_t MSM_G_LOG = msm_g_log();
         const uint32_t g = 1u << MSM_G_LOG;
         if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
@@ -386,7 +388,7 @@ struct MsmRunner {
             c.prof_end("msm_group_sum_kernel", pe, stream);
         }
         char *S2, *A2;
-        int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2);
+        int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2, stream);
         if (rc) return rc;
         char *S = (char *)cv.take(PB * nwin), *A = (char *)cv.take(PB * nwin);
         LW_MSM_WS_CHECK(cv);
@@ -400,62 +402,85 @@ struct MsmRunner {
         return LW_OK;
     }
 
-    // one pass over the pipeline; with cv.base == nullptr it only measures the workspace
-    int pipeline(const uint32_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, Carver &cv, char **S_out, char **A_out,
-                 uint32_t maxlen_hint) {
-        const uint32_t NW = fold_stride ? 1u : W;   // bucket sets: one per window, or one for all (folded SRS)
-        const uint32_t K = NW << (cbits - 1);   // signed digits: 2^(c-1) buckets per window, bucket j = multiplier j + 1
-        const bool dry = cv.base == nullptr;
-        const uint32_t CB = msm_sort_coarse_bins(cbits, NW, fold_stride ? (uint64_t)W * fold_stride : n);
-        uint32_t *coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
-        uint32_t *coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
-        uint32_t *maxlen_d = (uint32_t *)cv.take(256);
-        uint32_t *key_cnt = (uint32_t *)cv.take(4 * (size_t)K);        // zeroed with the counters above (contiguous)
-        uint32_t *key_cursor = (uint32_t *)cv.take(4 * (size_t)K);
-        uint32_t *coarse_off = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
-        uint32_t *sub_off = (uint32_t *)cv.take(4 * (size_t)(CB + 1));
-        uint32_t *off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
-        uint32_t *scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(K));
-        uint32_t *sorted = (uint32_t *)cv.take(4 * n * W);
-        uint64_t *items = (uint64_t *)cv.take(8 * n * W);
-        uint32_t *dig = (uint32_t *)cv.take(4 * (size_t)W * msm_sort_padded_points(n));
-        uint32_t maxlen = maxlen_hint;
+    // The windows of one MSM are processed as one or two independent SLICES [w0, w0 + Wh): each has its own sort arrays,
+    // bucket array and running sums, exactly as if it were an MSM with Wh windows; the digit matrix is shared.  Two
+    // slices let the memory-bound sort of the second and the latency-bound running sums of the first run on the side
+    // stream UNDER the compute-bound accumulation of the other slice (run() below).
+    struct Slice {
+        uint32_t w0 = 0, Wh = 0, NW = 0, K = 0, CB = 0;
+        uint32_t *coarse_cnt = nullptr, *coarse_cursor = nullptr, *maxlen_d = nullptr, *key_cnt = nullptr, *key_cursor = nullptr;
+        uint32_t *coarse_off = nullptr, *sub_off = nullptr, *off = nullptr, *scan_tmp = nullptr, *sorted = nullptr, *order_tmp = nullptr;
+        uint64_t *items = nullptr;
+        char *buckets = nullptr, *S = nullptr, *A = nullptr;
+        volatile uint32_t *maxlen_h = nullptr;   // pinned host word the sort's longest bucket is copied to
+    };
+
+    // carve-outs of a slice's sort; with cv.base == nullptr only the sizes are added up
+    int carve_sort(Slice &sl, size_t n, uint32_t cbits, Carver &cv) {
+        sl.NW = fold_stride ? 1u : sl.Wh;       // bucket sets: one per window, or one for all (folded SRS)
+        sl.K = sl.NW << (cbits - 1);            // signed digits: 2^(c-1) buckets per window, bucket j = multiplier j + 1
+        sl.CB = msm_sort_coarse_bins(cbits, sl.NW, fold_stride ? (uint64_t)W * fold_stride : n);
+        sl.coarse_cnt = (uint32_t *)cv.take(4 * (size_t)(sl.CB + 1));
+        sl.coarse_cursor = (uint32_t *)cv.take(4 * (size_t)(sl.CB + 1));
+        sl.maxlen_d = (uint32_t *)cv.take(256);
+        sl.key_cnt = (uint32_t *)cv.take(4 * (size_t)sl.K);        // zeroed with the counters above (contiguous)
+        sl.key_cursor = (uint32_t *)cv.take(4 * (size_t)sl.K);
+        sl.coarse_off = (uint32_t *)cv.take(4 * (size_t)(sl.CB + 1));
+        sl.sub_off = (uint32_t *)cv.take(4 * (size_t)(sl.CB + 1));
+        sl.off = (uint32_t *)cv.take(4 * (size_t)(sl.K + 1));
+        sl.scan_tmp = (uint32_t *)cv.take(msm_scan_scratch_bytes(sl.K));
+        sl.sorted = (uint32_t *)cv.take(4 * n * sl.Wh);
+        sl.items = (uint64_t *)cv.take(8 * n * sl.Wh);
+        sl.order_tmp = (uint32_t *)cv.take(msm_order_tmp_bytes());
+        sl.buckets = (char *)cv.take(PB * (size_t)sl.K);
         LW_MSM_WS_CHECK(cv);
-        if (!dry) {
-            // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
-            LW_HIP_CHECK(hipMemsetAsync(coarse_cnt, 0, (size_t)((char *)coarse_off - (char *)coarse_cnt), stream), LW_ERR_LAUNCH);
-            msm_launch_sort(c, d_scalars, (uint64_t)n, cbits, W, dig, coarse_cnt, coarse_off, coarse_cursor, items, sorted, off, K,
-                            maxlen_d, scan_tmp, sub_off, key_cnt, key_cursor, fold_stride, stream);
-            LW_HIP_CHECK(hipMemcpyAsync(&maxlen, maxlen_d, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
-            LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
-            if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
-        }
-        // accumulate rounds: while some bucket is longer than CH, cut every bucket into CH-sized pieces
+        return LW_OK;
+    }
+
+    // sort of the slice's windows (rows w0 .. w0 + Wh - 1 of the digit matrix) on stream `s`; the longest bucket lands in
+    // *sl.maxlen_h once `s` gets there
+    int launch_sort(Slice &sl, const uint32_t *dig, size_t n, uint32_t cbits, hipStream_t s) {
+        // coarse_cnt, coarse_cursor, maxlen, key_cnt and key_cursor are adjacent carve-outs: one memset clears them all
+        LW_HIP_CHECK(hipMemsetAsync(sl.coarse_cnt, 0, (size_t)((char *)sl.coarse_off - (char *)sl.coarse_cnt), s), LW_ERR_LAUNCH);
+        msm_launch_sort(c, dig + (size_t)sl.w0 * msm_sort_padded_points(n), (uint64_t)n, cbits, sl.Wh, sl.coarse_cnt, sl.coarse_off,
+                        sl.coarse_cursor, sl.items, sl.sorted, sl.off, sl.K, sl.maxlen_d, sl.scan_tmp, sl.sub_off, sl.key_cnt,
+                        sl.key_cursor, fold_stride, (uint64_t)sl.w0, s);
+        LW_HIP_CHECK(hipMemcpyAsync((void *)sl.maxlen_h, sl.maxlen_d, 4, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+
+    // accumulate rounds of a slice on stream `s`: while some bucket is longer than CH, cut every bucket into CH-sized
+    // pieces.  `maxlen`: the longest bucket (real run: from the sort; dry run: the worst case).  before_first_launch() is
+    // called once, right before the first accumulate kernel is enqueued.
+    template <class Hook>
+    int accumulate(Slice &sl, const void *d_points, size_t n, uint32_t maxlen, Carver &cv, hipStream_t s, Hook before_first_launch) {
+        const bool dry = cv.base == nullptr;
+        const uint32_t K = sl.K;
         const uint32_t CH = msm_ch((uint64_t)n * W);
         const bool ordered = msm_piece_order_enabled() != 0;   // first round only: later rounds sum equal numbers of partials
-        uint32_t *order_tmp = (uint32_t *)cv.take(msm_order_tmp_bytes());
-        const uint32_t *seg = off;
+        const uint32_t *seg = sl.off;
         const void *pts = d_points;         // first round: the caller's points through the sorted index list
-        const uint32_t *index = sorted;
+        const uint32_t *index = sl.sorted;
         uint64_t len = maxlen;             // longest segment
-        uint64_t items_bound = (uint64_t)n * W;   // upper bound on items in this round
+        uint64_t items_bound = (uint64_t)n * sl.Wh;   // upper bound on items in this round
         bool first = true;                 // (the dry run has no pointers to tell the rounds apart)
-        char *buckets = (char *)cv.take(PB * (size_t)K);
-        LW_MSM_WS_CHECK(cv);
+        bool hooked = false;
+        char *buckets = sl.buckets;
         auto launch = [&](const uint32_t *out_off, const uint32_t *perm_t, const uint32_t *perm_key, uint32_t total, void *pout,
                           const char *name) {
+            if (!hooked) { before_first_launch(); hooked = true; }
             const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
-            hipEvent_t pe = c.prof_begin(stream);
+            hipEvent_t pe = c.prof_begin(s);
             if (index && affine)
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, s, pts, index, seg,
                                    out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else if (out_off && C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, (C::ACC_WAVES == 2 ? 3 : C::ACC_WAVES), false>), dim3(blocks), dim3(MSM_THREADS), 0,
-                                   stream, pts, index, seg, out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
+                                   s, pts, index, seg, out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else
-                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, stream, pts, index, seg,
+                hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, false>), dim3(blocks), dim3(MSM_THREADS), 0, s, pts, index, seg,
                                    out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
-            c.prof_end(name, pe, stream);
+            c.prof_end(name, pe, s);
         };
         while (len > CH) {
             uint32_t *out_off = (uint32_t *)cv.take(4 * (size_t)(K + 1));
@@ -466,15 +491,15 @@ struct MsmRunner {
             uint32_t *perm_key = ord ? (uint32_t *)cv.take(4 * out_bound) : nullptr;
             LW_MSM_WS_CHECK(cv);
             if (!dry) {
-                msm_launch_scan(seg, out_off, K, (int)CH, maxlen_d, scan_tmp, stream);
+                msm_launch_scan(seg, out_off, K, (int)CH, sl.maxlen_d, sl.scan_tmp, s);
                 uint32_t total = 0;
-                LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
-                LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+                LW_HIP_CHECK(hipMemcpyAsync(&total, out_off + K, 4, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+                LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
                 if (total > out_bound) {
                     set_error("internal: MSM partial count %u exceeds bound %llu", total, (unsigned long long)out_bound);
                     return LW_ERR_LAUNCH;
                 }
-                if (ord) msm_launch_piece_order(c, seg, out_off, K, total, order_tmp, perm_t, perm_key, stream);
+                if (ord) msm_launch_piece_order(c, seg, out_off, K, total, sl.order_tmp, perm_t, perm_key, s);
                 if (total) launch(out_off, perm_t, perm_key, total, (void *)pout, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<partials>");
             }
             seg = out_off;
@@ -489,11 +514,23 @@ struct MsmRunner {
             uint32_t *perm_t = ord ? (uint32_t *)cv.take(4 * (size_t)K) : nullptr;
             LW_MSM_WS_CHECK(cv);
             if (!dry) {
-                if (ord) msm_launch_piece_order(c, seg, nullptr, K, K, order_tmp, perm_t, nullptr, stream);
+                if (ord) msm_launch_piece_order(c, seg, nullptr, K, K, sl.order_tmp, perm_t, nullptr, s);
                 launch(nullptr, perm_t, nullptr, K, nullptr, index ? "msm_accumulate_kernel" : "msm_accumulate_kernel<final>");
             }
         }
-        return reduce(buckets, 1u << (cbits - 1), NW, cv, S_out, A_out);
+        return LW_OK;
+    }
+
+    // `to` waits for everything enqueued on `from` so far (untimed event from the context pool)
+    int chain(hipStream_t from, hipStream_t to, std::vector<hipEvent_t> &taken, hipEvent_t *out = nullptr) {
+        hipEvent_t e = nullptr;
+        if (!c.sync_pool.empty()) { e = c.sync_pool.back(); c.sync_pool.pop_back(); }
+        else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return LW_ERR_LAUNCH; }
+        taken.push_back(e);
+        LW_HIP_CHECK(hipEventRecord(e, from), LW_ERR_LAUNCH);
+        if (to) LW_HIP_CHECK(hipStreamWaitEvent(to, e, 0), LW_ERR_LAUNCH);
+        if (out) *out = e;
+        return LW_OK;
     }
 
     int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {
@@ -517,23 +554,89 @@ struct MsmRunner {
                 set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
                 return LW_ERR_BAD_ARG;
             }
+            // Two slices from 2^22 points (below, the whole MSM is too short for the overlap to pay for a second set of
+            // launches); the folded SRS has one shared bucket set and stays whole.
+            static const bool split_env = [] { const char *e = tuning_env("LW_HIP_MSM_SLICES"); return !e || atoi(e) != 1; }();   // A/B only
+            const bool two = split_env && !fold_stride && W >= 4 && n >= ((size_t)1 << 22);
+            Slice sl[2];
+            const int ns = two ? 2 : 1;
+            sl[0].w0 = 0;
+            sl[0].Wh = two ? (W + 1) / 2 : W;
+            sl[1].w0 = sl[0].Wh;
+            sl[1].Wh = W - sl[0].Wh;
             // size the workspace for the worst case: one bucket holding every item.  A folded SRS sorts the items of all W
             // windows into one bucket set, so its longest bucket can hold n * W items (every scalar with the same digit in
             // every window), which takes more rounds of partial sums than n items do.
-            Carver dry{nullptr, 0};
-            char *S_d = nullptr, *A_d = nullptr;
             const uint64_t worst_len = fold_stride ? (uint64_t)n * W : (uint64_t)n;
-            int rc = pipeline(nullptr, nullptr, n, cbits, dry, &S_d, &A_d, (uint32_t)std::min<uint64_t>(worst_len, 0xffffffffu));
+            const uint32_t worst = (uint32_t)std::min<uint64_t>(worst_len, 0xffffffffu);
+            auto nothing = [] {};
+            auto plan = [&](Carver &cv, uint32_t **dig_out) -> int {   // every carve-out that does not depend on the data
+                *dig_out = (uint32_t *)cv.take(4 * (size_t)W * msm_sort_padded_points(n));
+                for (int k = 0; k < ns; k++) {
+                    int rc = carve_sort(sl[k], n, cbits, cv);
+                    if (rc) return rc;
+                }
+                return LW_OK;
+            };
+            Carver dry{nullptr, 0};
+            uint32_t *dig = nullptr;
+            int rc = plan(dry, &dig);
+            for (int k = 0; k < ns && !rc; k++) {
+                rc = accumulate(sl[k], nullptr, n, worst, dry, stream, nothing);
+                if (!rc) rc = reduce(sl[k].buckets, 1u << (cbits - 1), sl[k].NW, dry, &sl[k].S, &sl[k].A, stream);
+            }
             if (rc) return rc;
             if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
+            if (!c.pinned_words) LW_HIP_CHECK(hipHostMalloc((void **)&c.pinned_words, 256, hipHostMallocDefault), LW_ERR_ALLOC);
             Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};
-            rc = pipeline((const uint32_t *)d_scalars, d_points, n, cbits, cv, &S_d, &A_d, 0);
+            rc = plan(cv, &dig);
+            if (rc) return rc;
+            std::vector<hipEvent_t> taken;
+            struct Giveback { Context &c; std::vector<hipEvent_t> &t; ~Giveback() { for (hipEvent_t e : t) c.sync_pool.push_back(e); } } giveback{c, taken};
+            for (int k = 0; k < ns; k++) { sl[k].maxlen_h = c.pinned_words + k; *sl[k].maxlen_h = 0; }
+            hipStream_t side = nullptr;
+            if (two) {
+                rc = ensure_aux_stream(c);
+                if (rc) return rc;
+                side = c.aux_stream;
+            }
+            // digits of all windows, then the sort of the first slice, on the caller's stream
+            msm_launch_digits(c, (const uint32_t *)d_scalars, (uint64_t)n, cbits, W, dig, stream);
+            rc = launch_sort(sl[0], dig, n, cbits, stream);
+            if (rc) return rc;
+            LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+            if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
+            hipEvent_t sorted1 = nullptr;
+            int hook_rc = LW_OK;
+            auto start_side_sort = [&] {   // the second slice's sort starts when the first slice's accumulation does
+                if (!two) return;
+                hook_rc = chain(stream, side, taken);
+                if (!hook_rc) hook_rc = launch_sort(sl[1], dig, n, cbits, side);
+                if (!hook_rc) hook_rc = chain(side, nullptr, taken, &sorted1);
+            };
+            rc = accumulate(sl[0], d_points, n, *sl[0].maxlen_h, cv, stream, start_side_sort);
+            if (rc || hook_rc) return rc ? rc : hook_rc;
+            if (two) {
+                // running sums of the first slice on the side stream, under the second slice's accumulation
+                rc = chain(stream, side, taken);
+                if (!rc) rc = reduce(sl[0].buckets, 1u << (cbits - 1), sl[0].NW, cv, &sl[0].S, &sl[0].A, side);
+                if (rc) return rc;
+                LW_HIP_CHECK(hipEventSynchronize(sorted1), LW_ERR_LAUNCH);           // the host needs the longest bucket
+                LW_HIP_CHECK(hipStreamWaitEvent(stream, sorted1, 0), LW_ERR_LAUNCH);
+                rc = accumulate(sl[1], d_points, n, *sl[1].maxlen_h, cv, stream, nothing);
+                if (!rc) rc = reduce(sl[1].buckets, 1u << (cbits - 1), sl[1].NW, cv, &sl[1].S, &sl[1].A, stream);
+                if (!rc) rc = chain(side, stream, taken);
+            } else {
+                rc = reduce(sl[0].buckets, 1u << (cbits - 1), sl[0].NW, cv, &sl[0].S, &sl[0].A, stream);
+            }
             if (rc) return rc;
             LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
             const uint32_t NW = fold_stride ? 1u : W;
             std::vector<char> S(PB * NW), A(PB * NW);
-            LW_HIP_CHECK(hipMemcpyAsync(S.data(), S_d, PB * NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
-            LW_HIP_CHECK(hipMemcpyAsync(A.data(), A_d, PB * NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            for (int k = 0; k < ns; k++) {
+                LW_HIP_CHECK(hipMemcpyAsync(S.data() + PB * sl[k].w0, sl[k].S, PB * sl[k].NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+                LW_HIP_CHECK(hipMemcpyAsync(A.data() + PB * sl[k].w0, sl[k].A, PB * sl[k].NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
+            }
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             // window sum = sum (j + 1) * bucket[j] = S_w + A_w; fold most-significant first: acc <- 2^c * acc + sum_w  (pippenger.rs:101)
             auto window_sum = [&](uint32_t w) { return pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w)); };

@@ -49,6 +49,39 @@ def _offset_arg(field, offset):
     return np.ascontiguousarray(offset, dtype=field.dtype).reshape(-1)[:words].copy()
 
 
+class ResultBuffer:
+    """A pinned, resident result buffer from the library's pool (lw_hip_result_acquire / lw_hip_result_release): the
+    device-to-host copy into it runs at the PCIe rate, where a fresh numpy / Vec result pays one page fault per 4 KiB first.
+    `array` is a numpy view of the memory, valid until release() (or the end of the `with` block)."""
+
+    def __init__(self, field, n_elems):
+        self.field = field
+        self._p = C.c_void_p()
+        nbytes = n_elems * field.elem_bytes
+        check(L.lib().lw_hip_result_acquire(nbytes, C.byref(self._p)))
+        raw = (C.c_uint8 * nbytes).from_address(self._p.value)
+        shape = (n_elems,) if field.words == 1 else (n_elems, field.words)
+        self.array = np.frombuffer(raw, dtype=field.dtype).reshape(shape)
+
+    def release(self):
+        if self._p:
+            self.array = None
+            check(L.lib().lw_hip_result_release(self._p))
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 def evaluate_fft(field, coefficients, blowup_factor=1, domain_size=None, offset=None):
     """Polynomial::evaluate_fft (offset=None) / evaluate_offset_fft."""
     a = _as_elems(field, coefficients)
@@ -130,9 +163,10 @@ def bitrev_permutation(field, data):
     return out
 
 
-def ntt(field, data, inverse=False, log2n=None, batch=1, batch_stride=0, offset=None):
+def ntt(field, data, inverse=False, log2n=None, batch=1, batch_stride=0, offset=None, out=None):
     """Backend seam on host buffers (evaluate_fft_cuda / interpolate_fft_cuda equivalents,
-    math/src/fft/gpu/cuda/polynomial.rs:16-49): the slice is already power-of-two sized."""
+    math/src/fft/gpu/cuda/polynomial.rs:16-49): the slice is already power-of-two sized.  `out`: write the result into this
+    array (e.g. a ResultBuffer's) instead of a new one."""
     a = _as_elems(field, data)
     if log2n is None:
         n = a.shape[0] // batch
@@ -140,7 +174,10 @@ def ntt(field, data, inverse=False, log2n=None, batch=1, batch_stride=0, offset=
             from .errors import InputError
             raise InputError(f"Input length is {n}, which is not a power of two")
         log2n = n.bit_length() - 1
-    out = np.empty_like(a)
+    if out is None:
+        out = np.empty_like(a)
+    elif out.nbytes != a.nbytes or out.dtype != a.dtype or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous array of the input's size and type")
     off = _offset_arg(field, offset)
     check(L.lib().lw_hip_ntt(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD, _ptr(a), _ptr(out),
                              log2n, batch, batch_stride, _ptr(off)))

@@ -66,7 +66,9 @@ where
     let (field, layout) = hip_tag::<F, E>().ok_or_else(|| {
         FFTError::HipError(HipError::BadArgument(alloc::format!("no HIP kernels for {}", core::any::type_name::<F>())))
     })?;
-    lambdaworks_hip::ntt::<FieldElement<E>, FieldElement<F>>(field, layout, Dir::Forward, coeffs, None)
+    // SAFETY: hip_tag matched field_name() and the element sizes, so FieldElement<E> is the bare Montgomery limb array
+    // (math/src/field/element.rs:40-42): plain data, no Drop, every byte pattern the backend writes is a canonical residue.
+    unsafe { lambdaworks_hip::ntt_unchecked::<FieldElement<E>, FieldElement<F>>(field, layout, Dir::Forward, coeffs, None) }
         .map_err(|e| to_fft_error(e, coeffs.len()))
 }
 
@@ -80,7 +82,8 @@ where
         FFTError::HipError(HipError::BadArgument(alloc::format!("no HIP kernels for {}", core::any::type_name::<F>())))
     })?;
     // Dir::Inverse already multiplies by N^-1 (the reference does it on the CPU afterwards: cuda/polynomial.rs:46-48)
-    let coeffs = lambdaworks_hip::ntt::<FieldElement<E>, FieldElement<F>>(field, layout, Dir::Inverse, fft_evals, None)
+    // SAFETY: as in evaluate_fft_hip.
+    let coeffs = unsafe { lambdaworks_hip::ntt_unchecked::<FieldElement<E>, FieldElement<F>>(field, layout, Dir::Inverse, fft_evals, None) }
         .map_err(|e| to_fft_error(e, fft_evals.len()))?;
     Ok(Polynomial::new(&coeffs))
 }
@@ -95,7 +98,8 @@ where
     let (field, layout) = hip_tag::<F, E>().ok_or_else(|| {
         FFTError::HipError(HipError::BadArgument(alloc::format!("no HIP kernels for {}", core::any::type_name::<F>())))
     })?;
-    lambdaworks_hip::ntt(field, layout, Dir::Forward, coeffs, Some(offset)).map_err(|e| to_fft_error(e, coeffs.len()))
+    // SAFETY: as in evaluate_fft_hip.
+    unsafe { lambdaworks_hip::ntt_unchecked(field, layout, Dir::Forward, coeffs, Some(offset)) }.map_err(|e| to_fft_error(e, coeffs.len()))
 }
 
 #[cfg(test)]

@@ -104,6 +104,8 @@ extern "C" {
     pub fn lw_hip_curve_point_bytes(curve: Curve) -> usize;
 
     // ---- NTT backend seam
+    pub fn lw_hip_result_acquire(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn lw_hip_result_release(ptr: *mut c_void) -> c_int;
     pub fn lw_hip_ntt(field: Field, layout: Layout, dir: Dir, input: *const c_void, output: *mut c_void, log2n: u32,
                       batch: u32, batch_stride_elems: usize, coset_offset_or_null: *const c_void) -> c_int;
     pub fn lw_hip_ntt_device(field: Field, layout: Layout, dir: Dir, d_in: *const c_void, d_out: *mut c_void, log2n: u32,

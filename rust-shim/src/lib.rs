@@ -50,6 +50,19 @@ pub fn curve_point_bytes(curve: Curve) -> usize {
     unsafe { ffi::lw_hip_curve_point_bytes(curve) }
 }
 
+/// Marker for element types that are plain data: any bit pattern of `size_of::<Self>()` bytes is a valid value, there is
+/// no padding, no `Drop` and no interior pointer.  The library fills such values byte for byte.
+///
+/// # Safety
+/// Implement it only for types for which that holds — `[u64; N]`, and the `#[repr(transparent)]`-style newtype nesting of
+/// `FieldElement<MontgomeryBackendPrimeField<_, N>>` (math/src/field/element.rs:40-42, unsigned_integer/element.rs:29-37),
+/// which the typed modules under rust-shim/lambdaworks/ assert by size.
+pub unsafe trait Pod: Copy + 'static {}
+unsafe impl Pod for u32 {}
+unsafe impl Pod for u64 {}
+unsafe impl<const N: usize> Pod for [u64; N] {}
+unsafe impl<const N: usize> Pod for [u32; N] {}
+
 fn check_elems<T>(field: Field, layout: Layout) -> Result<(), HipError> {
     if size_of::<T>() != field_elem_bytes(field, layout) {
         return Err(HipError::BadArgument(format!(
@@ -67,7 +80,18 @@ fn check_elems<T>(field: Field, layout: Layout) -> Result<(), HipError> {
 /// (math/src/fft/gpu/cuda/polynomial.rs:16-49).  `input.len()` must be a power of two (it is the already padded
 /// coefficient / evaluation vector); `T` is the element type as it sits in memory.  `Dir::Inverse` results are already
 /// multiplied by N^-1.  `coset_offset`: one domain-field element (same layout's base word) or `None`.
-pub fn ntt<T, O>(field: Field, layout: Layout, dir: Dir, input: &[T], coset_offset: Option<&O>) -> Result<Vec<T>, HipError> {
+pub fn ntt<T: Pod, O: Pod>(field: Field, layout: Layout, dir: Dir, input: &[T], coset_offset: Option<&O>) -> Result<Vec<T>, HipError> {
+    // SAFETY: T and O are Pod.
+    unsafe { ntt_unchecked(field, layout, dir, input, coset_offset) }
+}
+
+/// [`ntt`] without the `Pod` bounds, for element types the caller vouches for (the typed lambdaworks modules: a
+/// `FieldElement<F>` whose `field_name()` and size matched a kernel family is the bare limb array).
+///
+/// # Safety
+/// `T` must be plain data of exactly the backend's element size: every byte pattern the library writes must be a valid
+/// `T`, `T` must not implement `Drop`; `O` likewise must be readable as raw bytes of one domain-field element.
+pub unsafe fn ntt_unchecked<T, O>(field: Field, layout: Layout, dir: Dir, input: &[T], coset_offset: Option<&O>) -> Result<Vec<T>, HipError> {
     check_elems::<T>(field, layout)?;
     let n = input.len();
     if n == 0 || !n.is_power_of_two() {
@@ -76,19 +100,77 @@ pub fn ntt<T, O>(field: Field, layout: Layout, dir: Dir, input: &[T], coset_offs
     let mut out: Vec<T> = Vec::with_capacity(n);
     let off = coset_offset.map_or(ptr::null(), |o| o as *const O as *const c_void);
     // SAFETY: `input` holds n elements of the size the library expects (checked above); `out` has capacity for n; the
-    // library writes exactly n elements on success and retains no pointer.
+    // library writes exactly n elements on success and retains no pointer.  (A fresh Vec has never been touched: the
+    // library asks for huge pages on it and populates it while the upload and the kernels run, include/lw_hip.h.)
     let rc = unsafe {
         ffi::lw_hip_ntt(field, layout, dir, input.as_ptr() as *const c_void, out.as_mut_ptr() as *mut c_void, n.trailing_zeros(), 1, 0, off)
     };
     check(rc)?;
-    // SAFETY: all n elements were initialised by the call above; T must be plain data (a lambdaworks FieldElement is).
+    // SAFETY: all n elements were initialised by the call above and T: Pod accepts any bytes.
     unsafe { out.set_len(n) };
     Ok(out)
 }
 
+/// The same transform into a caller-provided slice (`out.len() == input.len()`): no allocation, and the place to pass a
+/// [`HipBuf`] so that the download lands in pinned memory.
+pub fn ntt_into<T: Pod, O: Pod>(field: Field, layout: Layout, dir: Dir, input: &[T], out: &mut [T], coset_offset: Option<&O>) -> Result<(), HipError> {
+    check_elems::<T>(field, layout)?;
+    let n = input.len();
+    if n == 0 || !n.is_power_of_two() {
+        return Err(HipError::InputNotPowerOfTwo(format!("Input length is {n}, which is not a power of two")));
+    }
+    if out.len() != n {
+        return Err(HipError::BadArgument(format!("output slice holds {} elements, the transform has {n}", out.len())));
+    }
+    let off = coset_offset.map_or(ptr::null(), |o| o as *const O as *const c_void);
+    // SAFETY: both slices are valid for n elements of the checked size; `in` may alias `out`; nothing is retained.
+    let rc = unsafe {
+        ffi::lw_hip_ntt(field, layout, dir, input.as_ptr() as *const c_void, out.as_mut_ptr() as *mut c_void, n.trailing_zeros(), 1, 0, off)
+    };
+    check(rc)
+}
+
+/// A result buffer from the library's pool of pinned, resident host memory (`lw_hip_result_acquire`): derefs to `[T]`,
+/// goes back to the pool on drop.  Downloads into it run at the PCIe rate; a fresh `Vec` of the same size first pays one
+/// page fault per 4 KiB.  For provers that keep evaluation vectors alive across calls (the LDE columns of a STARK round).
+pub struct HipBuf<T: Pod> {
+    ptr: ptr::NonNull<T>,
+    len: usize,
+}
+impl<T: Pod> HipBuf<T> {
+    pub fn new(len: usize) -> Result<Self, HipError> {
+        let mut p: *mut c_void = ptr::null_mut();
+        // SAFETY: out pointer valid; the library returns memory aligned for any element type (page aligned).
+        check(unsafe { ffi::lw_hip_result_acquire(len.max(1) * size_of::<T>(), &mut p) })?;
+        // memory from the pool may hold an earlier result: any bytes are a valid T (Pod)
+        Ok(HipBuf { ptr: ptr::NonNull::new(p as *mut T).ok_or_else(|| HipError::AllocateMemory("null result buffer".into()))?, len })
+    }
+}
+impl<T: Pod> core::ops::Deref for HipBuf<T> {
+    type Target = [T];
+    fn deref(&self) -> &[T] {
+        // SAFETY: ptr is valid for len elements until drop.
+        unsafe { core::slice::from_raw_parts(self.ptr.as_ptr(), self.len) }
+    }
+}
+impl<T: Pod> core::ops::DerefMut for HipBuf<T> {
+    fn deref_mut(&mut self) -> &mut [T] {
+        // SAFETY: unique owner.
+        unsafe { core::slice::from_raw_parts_mut(self.ptr.as_ptr(), self.len) }
+    }
+}
+impl<T: Pod> Drop for HipBuf<T> {
+    fn drop(&mut self) {
+        // SAFETY: the pointer came from lw_hip_result_acquire and is released exactly once.
+        unsafe { ffi::lw_hip_result_release(self.ptr.as_ptr() as *mut c_void) };
+    }
+}
+// SAFETY: plain memory owned by the value.
+unsafe impl<T: Pod> Send for HipBuf<T> {}
+
 /// `batch` transforms of 2^log2n elements, `stride` elements apart, in place of a rayon loop over columns
 /// (provers/stark/src/trace.rs:186-190): one call, one upload.
-pub fn ntt_batch_in_place<T>(field: Field, layout: Layout, dir: Dir, data: &mut [T], log2n: u32, batch: u32, stride: usize) -> Result<(), HipError> {
+pub fn ntt_batch_in_place<T: Pod>(field: Field, layout: Layout, dir: Dir, data: &mut [T], log2n: u32, batch: u32, stride: usize) -> Result<(), HipError> {
     check_elems::<T>(field, layout)?;
     let n = 1usize << log2n;
     let stride_eff = if stride == 0 { n } else { stride };

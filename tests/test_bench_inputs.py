@@ -42,3 +42,24 @@ def test_synthetic_run_starting_at_zero_begins_with_the_identity():
     assert O.point_to_affine_ints(oid, cols[0]) is None
     g5 = O.ec_mul(oid, __import__("tests.util", fromlist=["generator"]).generator(oid), 5, 1)
     assert O.ec_eq(oid, cols[1], g5) and O.ec_eq(oid, cols[2], O.ec_add(oid, g5, g5))
+
+
+def test_cfg5_inputs_and_closed_form_match_the_oracle():
+    """bench_cfg.py synthesises BN254 G1 / G2 runs P_i = [s0 + i d]G and checks the timed 2^26 MSM against the closed form
+    [sum k_i (s0 + i d) mod r]G, both with its own Python big-integer arithmetic: pin that arithmetic to the oracle."""
+    import bench_cfg as B
+    from oracle import oracle as O
+    from tests import util
+    sc = B.scalars_mod(1000, 1, B.BN_R)
+    ks = O.array_to_ints(sc)
+    assert all(k < B.BN_R for k in ks)
+    s0, s1 = B.weighted_scalar_sums(sc, 12345)
+    assert s0 == sum(ks) and s1 == sum((12345 + i) * k for i, k in enumerate(ks))
+    for name, oid in (("bn254_g1", O.C_BN254_G1), ("bn254_g2", O.C_BN254_G2)):
+        pts = B.synth_run(name, 6, 5, 3, 9)
+        g = util.generator(oid)
+        for i in range(6):
+            assert O.ec_eq(oid, pts[i], O.ec_mul(oid, g, 5 + 3 * i, 4)), (name, i)
+        sc6 = B.scalars_mod(6, 3, B.BN_R)
+        a, b = B.weighted_scalar_sums(sc6, 0)
+        assert B.point_to_affine(name, O.msm(oid, sc6, pts)) == B.closed_form_msm(name, 5, 3, a, b, B.BN_R)

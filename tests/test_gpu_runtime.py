@@ -116,3 +116,31 @@ def test_init_takes_one_device_per_process_and_cross_step_keeps_tables_small():
     assert L.lw_hip_get_timings(C.byref(t)) == 0
     assert t.twiddle_bytes <= (1 << 17) * 32, t.twiddle_bytes
     assert np.array_equal(got.cpu().numpy().view(np.uint64), O.evaluate_fft(oid, a))
+
+
+def test_pooled_result_buffers():
+    """lw_hip_result_acquire / release: pinned result memory from the library's pool; results are the same bytes as through
+    a caller-owned buffer, buffers are recycled, foreign pointers are rejected."""
+    import ctypes as C
+    import numpy as np
+    from lambda_elliptic_curves_amd import _lib as L_
+    from lambda_elliptic_curves_amd import fft
+    from oracle import oracle as O
+    from tests import util
+    fld, oid = util.field_pairs()["stark252"]
+    a = util.rand_elems("stark252", 1 << 21, 11)            # 64 MiB: above the populate threshold
+    exp = O.evaluate_fft(oid, a)
+    fresh = fft.ntt(fld, a)                                  # fresh numpy buffer: huge-page advice + chunked copy-back path
+    assert np.array_equal(fresh, exp)
+    with fft.ResultBuffer(fld, 1 << 21) as rb:
+        first = rb._p.value
+        got = fft.ntt(fld, a, out=rb.array)
+        assert got is rb.array and np.array_equal(got, exp)
+    with fft.ResultBuffer(fld, 1 << 21) as rb2:              # same size again: the pool hands the buffer back
+        assert rb2._p.value == first
+        rb2.array[:] = 0
+        assert np.array_equal(fft.ntt(fld, a, out=rb2.array), exp)
+    junk = np.zeros(16, np.uint8)
+    assert L_.lib().lw_hip_result_release(junk.ctypes.data_as(C.c_void_p)) == L_.ERR_BAD_ARG
+    p = C.c_void_p()
+    assert L_.lib().lw_hip_result_acquire(0, C.byref(p)) == L_.ERR_BAD_ARG
