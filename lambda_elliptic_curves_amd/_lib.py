@@ -30,7 +30,7 @@ EXPORTS = [
     "lw_hip_ec_add_outer_device",
     "lw_hip_comm_unique_id", "lw_hip_comm_init", "lw_hip_comm_shutdown", "lw_hip_comm_info",
     "lw_hip_ntt_sharded_device", "lw_hip_ntt_sharded_selftest_device", "lw_hip_ntt_sharded_selftest_steps_device",
-    "lw_hip_msm_sharded_device",
+    "lw_hip_msm_sharded_device", "lw_hip_msm_sharded_selftest_device",
 ]
 
 
@@ -154,6 +154,8 @@ def lib():
     L.lw_hip_ntt_sharded_selftest_steps_device.restype = i
     L.lw_hip_msm_sharded_device.argtypes = [i, vp, vp, sz, vp, vp]
     L.lw_hip_msm_sharded_device.restype = i
+    L.lw_hip_msm_sharded_selftest_device.argtypes = [i, vp, vp, sz, u32, vp, vp]
+    L.lw_hip_msm_sharded_selftest_device.restype = i
     _lib = L
     return L
 

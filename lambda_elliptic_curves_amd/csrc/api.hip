@@ -149,7 +149,9 @@ void Context::release_all() {
     bb_coset.release();
     shard_a.release();
     shard_b.release();
+    shard_c.release();
     if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }
+    if (aux_hi) { (void)hipStreamDestroy(aux_hi); aux_hi = nullptr; }
     if (aux_fork) { (void)hipEventDestroy(aux_fork); aux_fork = nullptr; }
     if (aux_join) { (void)hipEventDestroy(aux_join); aux_join = nullptr; }
     if (order_event) { (void)hipEventDestroy(order_event); order_event = nullptr; }

@@ -11,10 +11,12 @@
 //                                   E  all-to-all + F local interleave -> my block of the natural-order result (optional)
 //                                 xGMI is a full mesh, so each all-to-all drives all G-1 links of a GPU at once; the payload
 //                                 per rank and exchange is (G-1)/G of the local shard.
-//   * lw_hip_msm_sharded_device   points/scalars sharded; every rank runs the whole Pippenger on its shard and the G
-//                                 partial sums (one point each) are all-gathered and added — RCCL has no user-defined
-//                                 reduction, so the north star's "bucket all-reduce" is an all-gather of tiny payloads
-//                                 followed by <= 7 group additions.
+//   * lw_hip_msm_sharded_device   points/scalars sharded; every rank accumulates its pairs into the full bucket array, an
+//                                 all-to-all gives rank g bucket range g of every window from everyone, rank g adds the G
+//                                 contributions and runs the running sums over its slice, and an all-gather of the
+//                                 per-slice (S, A) pairs lets every rank fold the result: the north star's "bucket
+//                                 all-reduce" as reduce-scatter (all-to-all + local group additions, RCCL has no
+//                                 user-defined reduction) + all-gather (second form) — msm_sharded_run below.
 //
 // The exchange schedule is written once against a small transport interface with two implementations: RCCL (one rank
 // per process) and an in-process simulator that walks all G virtual ranks on ONE device with device-to-device copies
@@ -37,6 +39,11 @@ int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t 
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
                hipStream_t stream, int scalars_montgomery, int affine_points);
 int msm_sum_points_host(lw_curve_t curve, const void *pts, size_t n, void *out);   // msm.hip
+uint32_t msm_window_bits_for(size_t n);                                              // msm.hip: the single-GPU window rule
+int msm_shard_accumulate(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, hipStream_t s,
+                         char **buckets);
+int msm_shard_reduce(Context &c, lw_curve_t curve, const char *recv, uint32_t G, uint32_t cbits, char *d_sa, hipStream_t s);
+int msm_shard_combine(lw_curve_t curve, const char *sa_all, uint32_t G, uint32_t cbits, void *out);
 uint32_t field_two_adicity(lw_field_t f);                                          // api.hip
 int check_field_layout(lw_field_t field, lw_layout_t layout);                      // api.hip
 
@@ -116,6 +123,8 @@ struct Transport {
     int first = 0, nlocal = 1;   // ranks [first, first + nlocal) live in this process
     virtual int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
                            hipStream_t s) = 0;
+    // all_gather: recv[h] of every local rank h receives, for every rank g, `bytes` bytes from g's send[g] at offset g * bytes
+    virtual int all_gather(const char *const *send, char *const *recv, size_t bytes, hipStream_t s) = 0;
     // collective agreement on a local status: LW_OK only if every rank passed LW_OK, else LW_ERR_COMM on all of them
     // (the failing rank reports its own code); synchronises `s`
     virtual int agree(int local_status, hipStream_t s) = 0;
@@ -138,6 +147,10 @@ struct RcclTransport : Transport {
                 }
             }
         LW_NCCL_CHECK(g_rccl.GroupEnd());
+        return LW_OK;
+    }
+    int all_gather(const char *const *send, char *const *recv, size_t bytes, hipStream_t s) override {
+        LW_NCCL_CHECK(g_rccl.AllGather(send[0], recv[0], bytes, ncclChar, g_comm.comm, s));
         return LW_OK;
     }
     int agree(int local_status, hipStream_t s) override {
@@ -166,6 +179,12 @@ struct SimTransport : Transport {   // G virtual ranks on one device
                     LW_HIP_CHECK(hipMemcpyAsync(recv[h] + b * bstride_bytes + (size_t)g * chunk_bytes,
                                                 send[g] + b * bstride_bytes + (size_t)h * chunk_bytes, chunk_bytes,
                                                 hipMemcpyDeviceToDevice, s), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+    int all_gather(const char *const *send, char *const *recv, size_t bytes, hipStream_t s) override {
+        for (int h = 0; h < G; h++)
+            for (int g = 0; g < G; g++)
+                LW_HIP_CHECK(hipMemcpyAsync(recv[h] + (size_t)g * bytes, send[g], bytes, hipMemcpyDeviceToDevice, s), LW_ERR_LAUNCH);
         return LW_OK;
     }
     int agree(int local_status, hipStream_t) override { return local_status; }   // all virtual ranks share one status
@@ -267,7 +286,7 @@ static int ntt_sharded_run(Context &c, Transport &tp, lw_field_t field, lw_layou
         if (rc0) return rc0;
         c.shard_prepared_key = shape_key;
     }
-    hipStream_t cs = c.aux_stream;   // exchanges
+    hipStream_t cs = c.aux_hi;   // exchanges: high priority, so that their kernels get CU slots under a running NTT kernel
     std::vector<const char *> src(nl);
     std::vector<char *> a(nl), b(nl), dst(nl);
     for (int i = 0; i < nl; i++) {
@@ -332,6 +351,90 @@ static int ntt_sharded_run(Context &c, Transport &tp, lw_field_t field, lw_layou
                          LW_ERR_LAUNCH);
     }
     return LW_OK;
+}
+
+// ---------------------------------------------------------------- sharded MSM: bucket-slice exchange (second form)
+// Every rank accumulates its pairs into the full bucket array [W][2^(c-1)] (no running sums yet); an all-to-all hands rank g
+// the bucket range [g*Bs, (g+1)*Bs) of every window from everyone; rank g adds the G contributions per bucket and runs the
+// running sums over ITS slice only — the bucket reduce, a constant ~4.7 ms per MSM at c = 20 whatever N is, shrinks with G —
+// and an all-gather of the per-slice (S, A) pairs (2 W points per rank) lets every rank fold the result.  This is the north
+// star's "bucket all-reduce": RCCL has no user-defined reduction, so the reduce-scatter half is an all-to-all plus local
+// group additions and the all-gather half carries the already reduced window partials.
+// scalars[i] / points[i] / n_local[i]: the pairs of local rank first + i.
+static int msm_sharded_run(Context &c, Transport &tp, lw_curve_t curve, const uint64_t *const *scalars, const void *const *points,
+                           const size_t *n_local, void *out_host, hipStream_t s) {
+    const int G = tp.G, nl = tp.nlocal;
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    // 1. window width: every rank must cut its scalars the same way.  All ranks learn all n_local (one tiny all-gather) and
+    //    apply the single-GPU rule to the largest shard.
+    if (c.small.ensure(8 * (size_t)(nl + G) * (size_t)nl + 256)) return LW_ERR_ALLOC;
+    uint64_t all_n[8] = {0};
+    {
+        std::vector<const char *> snd(nl);
+        std::vector<char *> rcv(nl);
+        uint64_t *d = (uint64_t *)c.small.p;
+        for (int i = 0; i < nl; i++) {
+            const uint64_t v = n_local[i];
+            LW_HIP_CHECK(hipMemcpyAsync(d + i, &v, 8, hipMemcpyHostToDevice, s), LW_ERR_LAUNCH);
+            snd[i] = (const char *)(d + i);
+            rcv[i] = (char *)(d + nl + (size_t)i * G);
+        }
+        LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);   // (&v is a stack temporary)
+        int rc = tp.all_gather(snd.data(), rcv.data(), 8, s);
+        if (rc) return rc;
+        LW_HIP_CHECK(hipMemcpyAsync(all_n, rcv[0], 8 * (size_t)G, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
+    }
+    uint64_t n_max = 0;
+    for (int g = 0; g < G; g++) n_max = all_n[g] > n_max ? all_n[g] : n_max;
+    uint32_t cbits = msm_window_bits_for((size_t)n_max);
+    uint32_t lg = 0;
+    while ((1 << lg) < G) lg++;
+    if (cbits < lg + 1) cbits = lg + 1;                       // at least one bucket per slice
+    const uint32_t W = (256 + cbits) / cbits;
+    const size_t B = (size_t)1 << (cbits - 1), Bs = B / G;
+    const size_t bucket_bytes = (size_t)W * B * pb, sa_bytes = 2 * (size_t)W * pb;
+    // 2. buffers, then the local accumulations; the outcome is agreed on before the big exchange (nobody may stay behind in it)
+    int prep = LW_OK;
+    if (c.shard_b.ensure(bucket_bytes * nl) || (nl > 1 && c.shard_a.ensure(bucket_bytes * nl)) ||
+        c.shard_c.ensure(sa_bytes * ((size_t)nl + (size_t)nl * G)))
+        prep = LW_ERR_ALLOC;
+    std::vector<const char *> snd(nl);
+    std::vector<char *> rcv(nl);
+    for (int i = 0; i < nl && !prep; i++) {
+        char *buckets = nullptr;
+        prep = msm_shard_accumulate(c, curve, scalars[i], points[i], n_local[i], cbits, s, &buckets);
+        if (prep) break;
+        if (nl > 1) {   // virtual ranks share one workspace: park this rank's buckets
+            char *park = (char *)c.shard_a.p + bucket_bytes * i;
+            LW_HIP_CHECK(hipMemcpyAsync(park, buckets, bucket_bytes, hipMemcpyDeviceToDevice, s), LW_ERR_LAUNCH);
+            buckets = park;
+        }
+        snd[i] = buckets;
+        rcv[i] = (char *)c.shard_b.p + bucket_bytes * i;
+    }
+    int rc = tp.agree(prep, s);
+    if (rc) return rc;
+    // 3. all-to-all: slice h of every window goes to rank h; received as [w][g][Bs]
+    rc = tp.all_to_all(snd.data(), rcv.data(), Bs * pb, W, B * pb, s);
+    if (rc) return rc;
+    // 4. add the G contributions, running sums over my slice
+    char *sa_send = (char *)c.shard_c.p, *sa_recv = sa_send + sa_bytes * nl;
+    int local_rc = LW_OK;
+    for (int i = 0; i < nl && !local_rc; i++) local_rc = msm_shard_reduce(c, curve, rcv[i], (uint32_t)G, cbits, sa_send + sa_bytes * i, s);
+    // 5. all-gather of the (S, A) pairs — entered even after a local failure, see ntt_sharded_run — and the fold on the host
+    for (int i = 0; i < nl; i++) {
+        snd[i] = sa_send + sa_bytes * i;
+        rcv[i] = sa_recv + sa_bytes * (size_t)G * i;
+    }
+    rc = tp.all_gather(snd.data(), rcv.data(), sa_bytes, s);
+    if (rc) return rc;
+    rc = tp.agree(local_rc, s);
+    if (rc) return rc;
+    std::vector<uint4> sa_host((sa_bytes * G + 15) / 16);
+    LW_HIP_CHECK(hipMemcpyAsync(sa_host.data(), rcv[0], sa_bytes * G, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
+    return msm_shard_combine(curve, (const char *)sa_host.data(), (uint32_t)G, cbits, out_host);
 }
 
 static int check_sharded_args(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *in, void *out, uint32_t L) {
@@ -457,40 +560,32 @@ int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const
     Entry en(hip_stream);
     if (en.rc) return en.rc;
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
-    Context &c = en.c;
-    const int G = g_comm.nranks;
-    // payload per rank: [status (16-byte header, so that the point keeps the 16-byte alignment its stores assume) | partial sum].  The local MSM runs first and its outcome travels WITH the point:
-    // a rank whose MSM failed still enters the all-gather (status != 0, identity payload), so nobody is left blocked in the
-    // collective, and every rank returns LW_ERR_COMM together.
-    constexpr size_t HDR = 16;
-    const size_t slot = HDR + pb;
-    std::vector<uint4> mine_v((slot + 15) / 16), all_v((slot * G + 15) / 16);   // 16-byte aligned host staging
-    char *mine = (char *)mine_v.data(), *all = (char *)all_v.data();
-    memset(mine, 0, slot);
-    const int local_rc = msm_device(c, curve, d_scalars, d_points, n_local, mine + HDR, en.stream, 0, 0);
-    const int64_t st = local_rc;
-    memcpy(mine, &st, 8);
-    if (local_rc) memset(mine + HDR, 0, pb);
-    if (c.shard_a.ensure(slot * (G + 1))) {
-        // cannot even stage 152 bytes: nothing to send — the peers will time out in RCCL; report it
-        return LW_ERR_ALLOC;
+    RcclTransport tp;
+    const uint64_t *sc[1] = {d_scalars};
+    const void *pt[1] = {d_points};
+    const size_t nn[1] = {n_local};
+    return msm_sharded_run(en.c, tp, curve, sc, pt, nn, out_point_host, en.stream);
+}
+
+// The same run with G = 2^log2_shards virtual ranks on ONE device: virtual rank g owns the pairs [g * n / G, (g + 1) * n / G).
+int lw_hip_msm_sharded_selftest_device(lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n_total, uint32_t log2_shards,
+                                       void *out_point_host, void *hip_stream) {
+    const size_t pb = lw_hip_curve_point_bytes(curve);
+    if (pb == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
+    if (log2_shards < 1 || log2_shards > 3) { set_error("self-test takes 2, 4 or 8 virtual ranks"); return LW_ERR_BAD_ARG; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    SimTransport tp(1 << log2_shards);
+    std::vector<const uint64_t *> sc(tp.G);
+    std::vector<const void *> pt(tp.G);
+    std::vector<size_t> nn(tp.G);
+    for (int g = 0; g < tp.G; g++) {
+        const size_t b0 = n_total * (size_t)g / tp.G, b1 = n_total * (size_t)(g + 1) / tp.G;
+        sc[g] = d_scalars + 4 * b0;
+        pt[g] = (const char *)d_points + pb * b0;
+        nn[g] = b1 - b0;
     }
-    char *d_send = (char *)c.shard_a.p, *d_recv = d_send + slot;
-    LW_HIP_CHECK(hipMemcpyAsync(d_send, mine, slot, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
-    LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, slot, ncclChar, g_comm.comm, en.stream));
-    LW_HIP_CHECK(hipMemcpyAsync(all, d_recv, slot * G, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
-    LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
-    if (local_rc) return local_rc;
-    std::vector<uint4> pts_v((pb * G + 15) / 16);
-    char *pts = (char *)pts_v.data();
-    for (int g = 0; g < G; g++) {
-        int64_t sg = 0;
-        memcpy(&sg, all + slot * g, 8);
-        if (sg) { set_error("rank %d failed its local MSM (status %lld)", g, (long long)sg); return LW_ERR_COMM; }
-        memcpy(pts + pb * g, all + slot * g + HDR, pb);
-    }
-    // <= 7 group additions on the host (same limb code as the device)
-    return msm_sum_points_host(curve, pts, (size_t)G, out_point_host);
+    return msm_sharded_run(en.c, tp, curve, sc.data(), pt.data(), nn.data(), out_point_host, en.stream);
 }
 
 }  // extern "C"

@@ -90,6 +90,7 @@ struct Context {
     DeviceBuf msm_prefix;    // running products of the batch inversion (msm_to_affine_kernel), one base-field element per point
     DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
     hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort
+    hipStream_t aux_hi = nullptr;       // high-priority side stream: short kernels that must get CU slots UNDER a long-running kernel of the caller's stream
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
     DeviceBuf pipe_tmp;               // intermediates of the device-resident pipelines (FRI layer evaluation, Groth16 cosets)
@@ -101,6 +102,7 @@ struct Context {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     DeviceBuf shard_a, shard_b;       // exchange buffers of the sharded (multi-GPU) entry points
+    DeviceBuf shard_c;                // (S, A) pairs of the sharded MSM's all-gather
     uint64_t shard_prepared_key = 0;  // shape of the last sharded NTT whose allocations every rank agreed on (comm.hip)
     std::vector<hipEvent_t> sync_pool;   // untimed events for cross-stream dependencies inside one call
     void release_all();               // frees every cached device object (shutdown / device change)

@@ -207,6 +207,27 @@ __device__ __forceinline__ uint32_t digit_of(const uint4 &v, int e) { return e =
 // coarse bin of an encoded digit (SORT_MAX_COARSE = the dummy slot of zero digits, which contribute nothing, pippenger.rs:78)
 __device__ __forceinline__ uint32_t coarse_bin(uint32_t enc, uint32_t fine_bits) { return enc ? (((enc >> 1) - 1) >> fine_bits) : SORT_MAX_COARSE; }
 
+// A/B only (LW_HIP_MSM_BALLOT=1): rank of an item among the items of its wave with the same bin by wave-wide
+// ballots — a match-any over the 10 bin bits, lane rank = popcount of the matching lanes below, one LDS atomic per
+// distinct bin and wave instead of one per item.  Returns the rank the plain atomicAdd(&h[bin], 1) would have returned
+// (up to the order inside the bin, which is irrelevant).
+__device__ __forceinline__ uint32_t ballot_rank_add(uint32_t *h, uint32_t bin) {
+    uint64_t m = __ballot(1);
+#pragma unroll
+    for (int b = 0; b < 10; b++) {
+        const uint32_t bit = (bin >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    const uint32_t lane = __lane_id();
+    const uint32_t below = __popcll(m & ((1ull << lane) - 1));
+    uint32_t base = 0;
+    if (below == 0) base = atomicAdd(&h[bin], (uint32_t)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    return base + below;
+}
+
+template <bool BALLOT = false>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
                                                                        uint32_t folded, uint32_t *coarse_cnt) {
     __shared__ uint32_t h[SORT_MAX_COARSE + 1];
@@ -216,16 +237,24 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_count_kernel(const ui
     const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
     const uint64_t q1 = min(n_pad / 4, q0 + SORT_PPB / 4);
     const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
+    if constexpr (BALLOT) {
+        for (uint64_t q = q0; q < q1; q += SORT_THREADS) {   // whole waves stay in the loop: ballots need every lane
+            const uint4 v = q + tid < q1 ? d4[q + tid] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) (void)ballot_rank_add(h, coarse_bin(digit_of(v, e), fine_bits));
+        }
+    } else {
     for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
         const uint4 v = d4[q];
 #pragma unroll
         for (int e = 0; e < 4; e++) atomicAdd(&h[coarse_bin(digit_of(v, e), fine_bits)], 1u);
     }
+    }
     __syncthreads();
     for (uint32_t b = tid; b < NB; b += SORT_THREADS)
         if (h[b]) atomicAdd(&coarse_cnt[(folded ? 0u : (w << hb)) + b], h[b]);
 }
-template <class ITEM>
+template <class ITEM, bool BALLOT = false>
 __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t *dig, uint64_t n_pad, uint32_t hb, uint32_t fine_bits,
                                                                  uint64_t idx_stride, uint32_t folded, uint32_t win0, const uint32_t *coarse_off,
                                                                  uint32_t *coarse_cursor, ItemMem<ITEM> items) {
@@ -243,10 +272,18 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
     const uint64_t q0 = (uint64_t)blockIdx.x * (SORT_PPB / 4);
     const uint64_t q1 = min(n_pad / 4, q0 + SORT_PPB / 4);
     const uint4 *d4 = reinterpret_cast<const uint4 *>(dig + (uint64_t)w * n_pad);
+    if constexpr (BALLOT) {
+        for (uint64_t q = q0; q < q1; q += SORT_THREADS) {
+            const uint4 v = q + tid < q1 ? d4[q + tid] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) (void)ballot_rank_add(h, coarse_bin(digit_of(v, e), fine_bits));
+        }
+    } else {
     for (uint64_t q = q0 + tid; q < q1; q += SORT_THREADS) {
         const uint4 v = d4[q];
 #pragma unroll
         for (int e = 0; e < 4; e++) atomicAdd(&h[coarse_bin(digit_of(v, e), fine_bits)], 1u);
+    }
     }
     __syncthreads();
     for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) {   // one global atomic per bin reserves this workgroup's run
@@ -268,7 +305,9 @@ __global__ __launch_bounds__(SORT_THREADS) void msm_coarse_kernel(const uint32_t
 #pragma unroll
         for (int l = 0; l < COARSE_LOADS; l++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) rk[l][e] = atomicAdd(&h[coarse_bin(digit_of(v[l], e), fine_bits)], 1u);
+            for (int e = 0; e < 4; e++)
+                rk[l][e] = BALLOT ? ballot_rank_add(h, coarse_bin(digit_of(v[l], e), fine_bits))
+                                  : atomicAdd(&h[coarse_bin(digit_of(v[l], e), fine_bits)], 1u);
         __syncthreads();
         for (uint32_t b = tid; b < SORT_MAX_COARSE; b += SORT_THREADS) pre[b] = h[b];   // zero digits stay in the dummy slot
         __syncthreads();
@@ -629,12 +668,16 @@ static void launch_sort_t(Context &c, uint64_t n, uint32_t cb, uint32_t W, const
     const uint32_t fine = sp.fine, hb = sp.hb;
     const dim3 grid((uint32_t)((n_pad + SORT_PPB - 1) / SORT_PPB), W);
     hipEvent_t pe = c.prof_begin(s);
-    hipLaunchKernelGGL(msm_coarse_count_kernel, grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, folded, coarse_cnt);
+    static const bool ballot = [] { const char *e = tuning_env("LW_HIP_MSM_BALLOT"); return e && atoi(e) == 1; }();   // A/B only
+    if (ballot) hipLaunchKernelGGL((msm_coarse_count_kernel<true>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, folded, coarse_cnt);
+    else hipLaunchKernelGGL((msm_coarse_count_kernel<false>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, folded, coarse_cnt);
     c.prof_end("msm_coarse_kernel<count>", pe, s);
     msm_launch_scan(coarse_cnt, coarse_off, CB, 0, maxlen + 1, scan_tmp, s);   // maxlen[1]: coarse max (unused)
     pe = c.prof_begin(s);
-    hipLaunchKernelGGL((msm_coarse_kernel<ITEM>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, fold_stride, folded,
-                       win0, (const uint32_t *)coarse_off, coarse_cursor, items);
+    if (ballot) hipLaunchKernelGGL((msm_coarse_kernel<ITEM, true>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, fold_stride, folded,
+                                   win0, (const uint32_t *)coarse_off, coarse_cursor, items);
+    else hipLaunchKernelGGL((msm_coarse_kernel<ITEM, false>), grid, dim3(SORT_THREADS), 0, s, (const uint32_t *)dig, n_pad, hb, fine, fold_stride, folded,
+                            win0, (const uint32_t *)coarse_off, coarse_cursor, items);
     c.prof_end("msm_coarse_kernel<scatter>", pe, s);
     // level B: sub-blocks of the coarse bins -> key counts -> key offsets (+ the longest bucket) -> sorted index list
     msm_launch_scan(coarse_off, sub_off, CB, (int)FINE_SUB, maxlen + 1, scan_tmp, s);
@@ -761,7 +804,9 @@ int ensure_aux_stream(Context &c) {
     // issue slots it leaves; with equal priorities the sort kernels queued behind the normalisation's workgroups
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    // (hipDeviceGetStreamPriorityRange: numerically lower = higher priority)
     if (hipStreamCreateWithPriority(&c.aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&c.aux_hi, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c.aux_join, hipEventDisableTiming) != hipSuccess) {
         set_error("cannot create the side stream");
@@ -829,6 +874,50 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
     }
     if (rc && join) (void)hipStreamSynchronize(c.aux_stream);   // do not leave the side stream running into a failed call's buffers
     return rc;
+}
+
+// ---- sharded MSM (comm.hip): per-curve dispatch of the three phases around the bucket-slice exchange ----
+#define LW_SHARD_DECL(SUFFIX)                                                                                                                 \
+    int msm_shard_accumulate_##SUFFIX(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_aff, size_t n, uint32_t cbits, char **buckets); \
+    int msm_shard_reduce_##SUFFIX(Context &c, hipStream_t s, const char *recv, uint32_t G, uint32_t cbits, char *d_sa);                        \
+    void msm_shard_combine_##SUFFIX(const char *sa_all, uint32_t G, uint32_t cbits, void *out);
+LW_SHARD_DECL(bls12381_g1) LW_SHARD_DECL(bn254_g1) LW_SHARD_DECL(bn254_g2) LW_SHARD_DECL(bls12381_g2)
+#undef LW_SHARD_DECL
+uint32_t msm_window_bits_for(size_t n) { return pick_window(n); }
+// local pairs -> dense bucket array in the context workspace.  The points are normalised first whatever n is, so that every
+// rank's buckets live on the same curve model (the isomorphic one where the curve has it) and can be added across ranks.
+int msm_shard_accumulate(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, hipStream_t s,
+                         char **buckets) {
+    if (n) {
+        if (c.msm_affine.ensure(msm_affine_bytes(curve, n))) return LW_ERR_ALLOC;
+        int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, s);
+        if (rc) return rc;
+    }
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_shard_accumulate_bls12381_g1(c, s, d_scalars, c.msm_affine.p, n, cbits, buckets);
+        case LW_CURVE_BN254_G1: return msm_shard_accumulate_bn254_g1(c, s, d_scalars, c.msm_affine.p, n, cbits, buckets);
+        case LW_CURVE_BN254_G2: return msm_shard_accumulate_bn254_g2(c, s, d_scalars, c.msm_affine.p, n, cbits, buckets);
+        case LW_CURVE_BLS12_381_G2: return msm_shard_accumulate_bls12381_g2(c, s, d_scalars, c.msm_affine.p, n, cbits, buckets);
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
+int msm_shard_reduce(Context &c, lw_curve_t curve, const char *recv, uint32_t G, uint32_t cbits, char *d_sa, hipStream_t s) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: return msm_shard_reduce_bls12381_g1(c, s, recv, G, cbits, d_sa);
+        case LW_CURVE_BN254_G1: return msm_shard_reduce_bn254_g1(c, s, recv, G, cbits, d_sa);
+        case LW_CURVE_BN254_G2: return msm_shard_reduce_bn254_g2(c, s, recv, G, cbits, d_sa);
+        case LW_CURVE_BLS12_381_G2: return msm_shard_reduce_bls12381_g2(c, s, recv, G, cbits, d_sa);
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
+}
+int msm_shard_combine(lw_curve_t curve, const char *sa_all, uint32_t G, uint32_t cbits, void *out) {
+    switch (curve) {
+        case LW_CURVE_BLS12_381_G1: msm_shard_combine_bls12381_g1(sa_all, G, cbits, out); return LW_OK;
+        case LW_CURVE_BN254_G1: msm_shard_combine_bn254_g1(sa_all, G, cbits, out); return LW_OK;
+        case LW_CURVE_BN254_G2: msm_shard_combine_bn254_g2(sa_all, G, cbits, out); return LW_OK;
+        case LW_CURVE_BLS12_381_G2: msm_shard_combine_bls12381_g2(sa_all, G, cbits, out); return LW_OK;
+        default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
+    }
 }
 
 // Sum of a few projective points on the host, normalised like every MSM result (the combine step of the sharded MSM).

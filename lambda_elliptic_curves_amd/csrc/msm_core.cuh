@@ -265,6 +265,25 @@ __global__ void msm_combine_kernel(const void *S2, const void *A2, uint32_t k, u
     pt_st<C>(A, w, pt_ld<C>(A2, w));
 }
 
+// ---------------------------------------------------------------- sharded MSM (comm.hip): bucket-slice exchange
+// buckets[i] = identity (a rank without pairs still owns a slice of everybody's buckets)
+template <class C>
+__global__ void msm_fill_identity_kernel(void *buckets, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) pt_st<C>(buckets, i, pt_identity<C>());
+}
+// recv[w][g][j]: bucket j of MY bucket range in window w as rank g accumulated it.  out[w][j] = sum over g.
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_slice_sum_kernel(const void *recv, uint32_t G, uint32_t Bs, uint32_t nwin, void *out) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)nwin * Bs) return;
+    const uint64_t w = t / Bs, j = t - w * Bs;
+    Point<C> acc = pt_ld<C>(recv, (w * G) * Bs + j);
+#pragma nounroll
+    for (uint32_t g = 1; g < G; g++) acc = pt_add<C>(acc, pt_ld<C>(recv, (w * G + g) * Bs + j));
+    pt_st<C>(out, t, acc);
+}
+
 // ---------------------------------------------------------------- host orchestration
 struct Carver {   // bump allocator over the context workspace
     char *base;
@@ -533,6 +552,124 @@ struct MsmRunner {
         return LW_OK;
     }
 
+    // window sums -> the MSM: fold most-significant first, acc <- 2^c * acc + sum_w (pippenger.rs:101).  a_top: the plain sum of
+    // the top slot's buckets, needed when c divides 256 (see below).
+    static Point<C> fold_windows(const std::vector<Point<C>> &wsum, const Point<C> &a_top, uint32_t cbits, uint32_t W, bool folded) {
+        const uint32_t NW = folded ? 1u : W;
+        uint32_t top = NW - 1;
+        Point<C> result = wsum[top];   // folded: the copies already carry the 2^(c w) factors, one sum is the result
+        if (!folded && (W - 1) * cbits == 256) {
+            // the top window's values above 2^(c-1) live in slot W-1 with 2^(c-1) taken off (msm_digits_kernel): both slots
+            // weigh 2^(256-c); slot W-1 owes 2^(c-1) times its plain sum
+            Point<C> extra = a_top;
+            for (uint32_t i = 0; i + 1 < cbits; i++) extra = pt_dbl<C>(extra);
+            top--;
+            result = pt_add<C>(pt_add<C>(result, extra), wsum[top]);
+        }
+        for (uint32_t w = top; w-- > 0;) {
+            for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
+            result = pt_add<C>(result, wsum[w]);
+        }
+        return result;
+    }
+
+    // ---- sharded MSM (comm.hip msm_sharded_run): three phases around the bucket-slice exchange --------------------------
+    // Phase 1: digits + sort + accumulation of the local pairs with the window width all ranks agreed on; leaves the dense
+    // bucket array [W][2^(c-1)] in the context workspace (*buckets_out, valid until the next MSM on this context).
+    int shard_accumulate(const uint64_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, char **buckets_out) {
+        if ((n >> 31) || (((uint64_t)n * ((256 + cbits) / cbits)) >> 32)) { set_error("MSM shard of %zu points: index width", n); return LW_ERR_BAD_ARG; }
+        W = (256 + cbits) / cbits;
+        Slice sl;
+        sl.w0 = 0;
+        sl.Wh = W;
+        if (n == 0) {   // no pairs here: identity buckets (this rank still owns a slice of everybody's)
+            const uint64_t K = (uint64_t)W << (cbits - 1);
+            if (c.msm_ws.ensure(PB * K + 4096)) return LW_ERR_ALLOC;
+            hipLaunchKernelGGL((msm_fill_identity_kernel<C>), dim3((uint32_t)((K + 255) / 256)), dim3(256), 0, stream, c.msm_ws.p, K);
+            LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+            *buckets_out = (char *)c.msm_ws.p;
+            return LW_OK;
+        }
+        auto nothing = [] {};
+        Carver dry{nullptr, 0};
+        uint32_t *dig = (uint32_t *)dry.take(4 * (size_t)W * msm_sort_padded_points(n));
+        int rc = carve_sort(sl, n, cbits, dry);
+        if (!rc) rc = accumulate(sl, nullptr, n, (uint32_t)std::min<size_t>(n, 0xffffffffu), dry, stream, nothing);
+        if (rc) return rc;
+        if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;
+        if (!c.pinned_words) LW_HIP_CHECK(hipHostMalloc((void **)&c.pinned_words, 256, hipHostMallocDefault), LW_ERR_ALLOC);
+        Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};
+        dig = (uint32_t *)cv.take(4 * (size_t)W * msm_sort_padded_points(n));
+        rc = carve_sort(sl, n, cbits, cv);
+        if (rc) return rc;
+        sl.maxlen_h = c.pinned_words;
+        *sl.maxlen_h = 0;
+        msm_launch_digits(c, (const uint32_t *)d_scalars, (uint64_t)n, cbits, W, dig, stream);
+        rc = launch_sort(sl, dig, n, cbits, stream);
+        if (rc) return rc;
+        LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
+        if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);
+        rc = accumulate(sl, d_points, n, *sl.maxlen_h, cv, stream, nothing);
+        if (rc) return rc;
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        *buckets_out = sl.buckets;
+        return LW_OK;
+    }
+
+    // Phase 2: recv[w][g][j] = bucket j of my bucket range [rank*Bs, (rank+1)*Bs) of window w as rank g accumulated it
+    // (Bs = 2^(c-1) / G).  Adds the G contributions and runs the running sums over the slice:
+    // d_sa[w] = S_w = sum_d d * B[d], d_sa[W + w] = A_w = sum_d B[d], d counted from 0 INSIDE the slice — the slice's
+    // offset is applied in phase 3.  The bucket reduce of an MSM thus costs 1/G of the single-GPU one per rank.
+    int shard_reduce(const char *recv, uint32_t G, uint32_t cbits, char *d_sa) {
+        W = (256 + cbits) / cbits;
+        const uint32_t Bs = (1u << (cbits - 1)) / G;
+        if (Bs == 0 || Bs * G != (1u << (cbits - 1))) { set_error("2^%u buckets cannot be cut into %u slices", cbits - 1, G); return LW_ERR_BAD_ARG; }
+        char *S_d = nullptr, *A_d = nullptr;
+        Carver dry{nullptr, 0};
+        (void)dry.take(PB * (size_t)W * Bs);
+        int rc = reduce(nullptr, Bs, W, dry, &S_d, &A_d, stream);
+        if (rc) return rc;
+        if (c.msm_ws.ensure(dry.used + 4096)) return LW_ERR_ALLOC;   // (the local buckets have left through the exchange)
+        Carver cv{(char *)c.msm_ws.p, c.msm_ws.bytes};
+        char *summed = (char *)cv.take(PB * (size_t)W * Bs);
+        hipEvent_t pe = c.prof_begin(stream);
+        hipLaunchKernelGGL((msm_slice_sum_kernel<C>), dim3((uint32_t)(((uint64_t)W * Bs + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                           stream, (const void *)recv, G, Bs, W, (void *)summed);
+        c.prof_end("msm_slice_sum_kernel", pe, stream);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
+        rc = reduce(summed, Bs, W, cv, &S_d, &A_d, stream);
+        if (rc) return rc;
+        LW_HIP_CHECK(hipMemcpyAsync(d_sa, S_d, PB * W, hipMemcpyDeviceToDevice, stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipMemcpyAsync(d_sa + PB * W, A_d, PB * W, hipMemcpyDeviceToDevice, stream), LW_ERR_LAUNCH);
+        return LW_OK;
+    }
+
+    // Phase 3 (host, every rank the same): sa_all[g] = rank g's (S[W], A[W]).  Bucket d of slice g is bucket g*Bs + d of the
+    // window, multiplier g*Bs + d + 1, so   window sum = sum_g (S_g + A_g) + Bs * sum_g g * A_g.
+    static void shard_combine_host(const char *sa_all, uint32_t G, uint32_t cbits, void *out_host) {
+        const uint32_t W = (256 + cbits) / cbits, Bs = (1u << (cbits - 1)) / G;
+        uint32_t lgBs = 0;
+        while ((1u << lgBs) < Bs) lgBs++;
+        std::vector<Point<C>> wsum(W);
+        Point<C> a_top = pt_identity<C>();
+        for (uint32_t w = 0; w < W; w++) {
+            Point<C> x = pt_identity<C>(), run = pt_identity<C>(), t = pt_identity<C>(), a_all = pt_identity<C>();
+            for (uint32_t g = G; g-- > 0;) {   // sum_g g * A_g by a running sum from the top slice (pippenger.rs:85-98, over ranks)
+                const char *sg = sa_all + (size_t)g * 2 * W * PB;
+                const Point<C> S = pt_load<C>(sg + PB * w), A = pt_load<C>(sg + PB * (W + w));
+                x = pt_add<C>(x, pt_add<C>(S, A));
+                a_all = pt_add<C>(a_all, A);
+                if (g > 0) { run = pt_add<C>(run, A); t = pt_add<C>(t, run); }
+            }
+            for (uint32_t i = 0; i < lgBs; i++) t = pt_dbl<C>(t);
+            wsum[w] = pt_add<C>(x, t);
+            if (w + 1 == W) a_top = a_all;
+        }
+        Point<C> result = fold_windows(wsum, a_top, cbits, W, false);
+        result = pt_unmap_result<C>(pt_to_affine<C>(result));
+        pt_store<C>(out_host, result);
+    }
+
     int run(const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host) {
         Point<C> result = pt_identity<C>();
         if (n > 0) {
@@ -554,9 +691,13 @@ struct MsmRunner {
                 set_error("MSM of %zu points x %u windows overflows 32-bit item offsets; shard the input", n, W);
                 return LW_ERR_BAD_ARG;
             }
-            // Two slices from 2^22 points (below, the whole MSM is too short for the overlap to pay for a second set of
-            // launches); the folded SRS has one shared bucket set and stays whole.
-            static const bool split_env = [] { const char *e = tuning_env("LW_HIP_MSM_SLICES"); return !e || atoi(e) != 1; }();   // A/B only
+            // Two slices (LW_HIP_MSM_SLICES=2, off by default): MEASURED AND DROPPED as the default — with the second slice's
+            // sort and the first slice's running sums on a high-priority side stream under the other slice's accumulation,
+            // 2^24 BLS12-381 G1 took 45.6 ms against 45.2-45.6 ms in one slice, and 2^22 15.6 against 14.8
+            // (profiles/r03_ab_msm_slices.txt): the accumulate kernel is bound by VALU issue with 3 waves per SIMD hiding its
+            // gathers, so every wave slot, LDS allocation and issue cycle the side kernels take comes out of it one for one
+            // (it ran 1.3 ms longer; the side kernels, starved, took 3-5x their standalone time).
+            static const bool split_env = [] { const char *e = tuning_env("LW_HIP_MSM_SLICES"); return e && atoi(e) == 2; }();   // A/B only
             const bool two = split_env && !fold_stride && W >= 4 && n >= ((size_t)1 << 22);
             Slice sl[2];
             const int ns = two ? 2 : 1;
@@ -598,7 +739,7 @@ struct MsmRunner {
             if (two) {
                 rc = ensure_aux_stream(c);
                 if (rc) return rc;
-                side = c.aux_stream;
+                side = c.aux_hi;   // high priority: its short kernels take CU slots as the long accumulate kernel's workgroups retire
             }
             // digits of all windows, then the sort of the first slice, on the caller's stream
             msm_launch_digits(c, (const uint32_t *)d_scalars, (uint64_t)n, cbits, W, dig, stream);
@@ -638,22 +779,10 @@ struct MsmRunner {
                 LW_HIP_CHECK(hipMemcpyAsync(A.data() + PB * sl[k].w0, sl[k].A, PB * sl[k].NW, hipMemcpyDeviceToHost, stream), LW_ERR_LAUNCH);
             }
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
-            // window sum = sum (j + 1) * bucket[j] = S_w + A_w; fold most-significant first: acc <- 2^c * acc + sum_w  (pippenger.rs:101)
-            auto window_sum = [&](uint32_t w) { return pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w)); };
-            uint32_t top = NW - 1;
-            result = window_sum(top);   // folded: the copies already carry the 2^(c w) factors, one sum is the result
-            if (!fold_stride && (W - 1) * cbits == 256) {
-                // the top window's values above 2^(c-1) live in slot W-1 with 2^(c-1) taken off (msm_digits_kernel): both slots
-                // weigh 2^(256-c); slot W-1 owes 2^(c-1) times its plain sum
-                Point<C> extra = pt_load<C>(A.data() + PB * top);
-                for (uint32_t i = 0; i + 1 < cbits; i++) extra = pt_dbl<C>(extra);
-                top--;
-                result = pt_add<C>(pt_add<C>(result, extra), window_sum(top));
-            }
-            for (uint32_t w = top; w-- > 0;) {
-                for (uint32_t i = 0; i < cbits; i++) result = pt_dbl<C>(result);
-                result = pt_add<C>(result, window_sum(w));
-            }
+            // window sum = sum (j + 1) * bucket[j] = S_w + A_w
+            std::vector<Point<C>> wsum(NW);
+            for (uint32_t w = 0; w < NW; w++) wsum[w] = pt_add<C>(pt_load<C>(S.data() + PB * w), pt_load<C>(A.data() + PB * w));
+            result = fold_windows(wsum, pt_load<C>(A.data() + PB * (NW - 1)), cbits, W, fold_stride != 0);
         }
         result = pt_unmap_result<C>(pt_to_affine<C>(result));
         pt_store<C>(out_host, result);
@@ -691,6 +820,20 @@ struct MsmRunner {
         MsmRunner<typename IsoOf<CURVE>::type> r{c, s, 0};                                                                         \
         return r.build_fold(d_rows, n, cbits);                                                                                     \
     }                                      \
+    /* sharded MSM phases: always on the normalised (affine) rows, i.e. on IsoOf<CURVE> where the curve has a cheaper model */  \
+    int msm_shard_accumulate_##SUFFIX(Context &c, hipStream_t s, const uint64_t *d_scalars, const void *d_aff, size_t n, uint32_t cbits, \
+                                      char **buckets) {                                                                             \
+        MsmRunner<typename IsoOf<CURVE>::type> r{c, s, 0};                                                                         \
+        r.affine = true;                                                                                                           \
+        return r.shard_accumulate(d_scalars, d_aff, n, cbits, buckets);                                                            \
+    }                                                                                                                              \
+    int msm_shard_reduce_##SUFFIX(Context &c, hipStream_t s, const char *recv, uint32_t G, uint32_t cbits, char *d_sa) {           \
+        MsmRunner<typename IsoOf<CURVE>::type> r{c, s, 0};                                                                         \
+        return r.shard_reduce(recv, G, cbits, d_sa);                                                                               \
+    }                                                                                                                              \
+    void msm_shard_combine_##SUFFIX(const char *sa_all, uint32_t G, uint32_t cbits, void *out) {                                   \
+        MsmRunner<typename IsoOf<CURVE>::type>::shard_combine_host(sa_all, G, cbits, out);                                         \
+    }                                                                                                                              \
     int ec_add_outer_##SUFFIX(Context &c, hipStream_t s, const void *d_rows, uint32_t m, const void *d_cols, uint32_t k, void *d_out) { \
         MsmRunner<CURVE> r{c, s, 0};                                                                                               \
         return r.add_outer(d_rows, m, d_cols, k, d_out);                                                                           \

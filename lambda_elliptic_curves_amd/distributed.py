@@ -8,9 +8,12 @@ single-device API on the concatenated input.
                 (lw_hip_ntt_device) [-> all-to-all + local interleave for natural block order].
                 xGMI is a full mesh, so every all-to-all keeps all 7 links busy; payload per rank and exchange
                 is (G-1)/G of the local shard.
-* msm_sharded   points (and scalars) are sharded; each rank runs the full Pippenger on its shard, the G partial
-                sums are all-gathered (one point each) and added.  RCCL has no user-defined reduction, so the
-                "bucket all-reduce" of the north star is an all-gather + local group adds of tiny payloads.
+* msm_sharded   points (and scalars) are sharded.  HipComm (the library, csrc/comm.hip msm_sharded_run): every rank
+                accumulates its pairs into the full bucket array, an all-to-all hands rank g bucket range g of every
+                window, rank g sums the G contributions and runs the running sums over its slice, an all-gather of the
+                per-slice sums lets every rank fold the result — the north star's "bucket all-reduce" as
+                reduce-scatter + all-gather (RCCL has no user-defined reduction).  The TorchDistComm / SimComm path
+                below is the simpler first form (all-gather of one partial sum per rank), kept for the CPU gloo test.
 * batches with batch >= G need no collective: give each rank whole columns (fft.ntt_device per rank).
 
 The production path is `HipComm`: the communicator and the whole exchange schedule live INSIDE the C library
@@ -235,6 +238,15 @@ def ntt_sharded_selftest_steps(field, x_full, log2n_total, log2_shards, stop_aft
     check(L.lib().lw_hip_ntt_sharded_selftest_steps_device(field.field, field.layout, L.DIR_INVERSE if inverse else L.DIR_FORWARD,
                                                            C.c_void_p(x_full.data_ptr()), C.c_void_p(out.data_ptr()), log2n_total,
                                                            log2_shards, batch, 1 if natural_output else 0, stop_after, _stream_ptr()))
+    return out
+
+
+def msm_sharded_selftest(curve, t_scalars, t_points, n_total, log2_shards):
+    """lw_hip_msm_sharded_selftest_device: the bucket-slice exchange schedule of the sharded MSM (csrc/comm.hip
+    msm_sharded_run) with 2^log2_shards virtual ranks on one device."""
+    out = np.zeros(curve.point_words, dtype=np.uint64)
+    check(L.lib().lw_hip_msm_sharded_selftest_device(curve.curve, C.c_void_p(t_scalars.data_ptr()), C.c_void_p(t_points.data_ptr()), n_total,
+                                                     log2_shards, out.ctypes.data_as(C.c_void_p), _stream_ptr()))
     return out
 
 

@@ -136,6 +136,8 @@ extern "C" {
                                                     natural_output: c_int, stop_after: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn lw_hip_msm_sharded_device(curve: Curve, d_scalars: *const u64, d_points: *const c_void, n_local: usize,
                                      out_point_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
+    pub fn lw_hip_msm_sharded_selftest_device(curve: Curve, d_scalars: *const u64, d_points: *const c_void, n_total: usize, log2_shards: u32,
+                                              out_point_host: *mut c_void, hip_stream: *mut c_void) -> c_int;
 
     // ---- Polynomial FFT API (host buffers, reference semantics)
     pub fn lw_polynomial_evaluate_fft(field: Field, layout: Layout, coeffs: *const c_void, n_coeffs: usize, blowup_factor: usize,

@@ -184,6 +184,40 @@ def test_library_sharded_large_stark252_2_22_over_8():
     assert np.array_equal(got.cpu().numpy().view(np.uint64), O.evaluate_fft(oid, full))
 
 
+@pytest.mark.parametrize("name", ["bls12_381_g1", "bn254_g1", "bn254_g2", "bls12_381_g2"])
+@pytest.mark.parametrize("lg,n", [(1, 257), (2, 3001), (3, 5000), (3, 5)])
+def test_sharded_msm_bucket_slice_exchange_selftest(name, lg, n):
+    """lw_hip_msm_sharded_selftest_device: the schedule RCCL runs for the sharded MSM (local accumulation -> all-to-all of
+    bucket slices -> per-slice sums and running sums -> all-gather of the (S, A) pairs -> fold), with 2^lg virtual ranks on
+    this one GPU, against the oracle's msm over all pairs.  Uneven shards, shards without pairs (n = 5 over 8 ranks),
+    adversarial scalars (all windows at the signed-digit boundary, 2^256 - 1, r - 1, zero)."""
+    from lambda_elliptic_curves_amd import distributed as D
+    from oracle import bigint_def as DD
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 3100 + n + lg)
+    r = DD.P_FR381 if name.startswith("bls") else DD.P_FR254
+    ks = [int(O.limbs_to_int(row)) for row in scalars]
+    for i, v in enumerate([(1 << 256) - 1, r - 1, 0, sum((1 << 7) << (8 * w) for w in range(32)), sum(((1 << 7) + 1) << (8 * w) for w in range(32))]):
+        ks[(i * 7) % n] = v
+    scalars = O.ints_to_array(ks, 4)
+    points = points.copy()
+    points[n // 2] = O.ec_neutral(oid)
+    got = D.msm_sharded_selftest(crv, _as_t(scalars), _as_t(points), n, lg)
+    exp = O.parallel_msm_with(oid, scalars, points, 8, 8)
+    assert O.point_to_affine_ints(oid, got) == O.point_to_affine_ints(oid, exp)
+
+
+def test_sharded_msm_selftest_wide_windows_2_18():
+    # 2^18 BN254 G1 pairs over 8 virtual ranks: 2^15 per rank, c = 16 (the wide-item sort), 2^12 buckets per slice
+    from lambda_elliptic_curves_amd import distributed as D
+    crv, oid = util.curve_pairs()["bn254_g1"]
+    n = 1 << 18
+    scalars, points = util.msm_case(oid, n, 3218, threads=util.host_threads())
+    got = D.msm_sharded_selftest(crv, _as_t(scalars), _as_t(points), n, 3)
+    exp = O.parallel_msm_with(oid, scalars, points, 14, util.host_threads())
+    assert O.point_to_affine_ints(oid, got) == O.point_to_affine_ints(oid, exp)
+
+
 def test_rccl_communicator_one_rank_through_the_c_abi():
     # The library-owned RCCL communicator with nranks = 1: librccl is loaded, ncclCommInitRank runs, and the sharded
     # entry points go through ncclSend/ncclRecv (to self) and ncclAllGather on the real transport.

@@ -123,6 +123,31 @@ def test_babybear_4_columns_2_24_match_oracle(name):
         assert torch.equal(t_out, t_in)
 
 
+def test_babybear_ext4_2_24_matches_oracle():
+    """Degree4BabyBearExtensionField values over a base-field domain at 2^24 (the size the ext4 timing is quoted on): an E-valued
+    transform with F twiddles is four interleaved base transforms (quartic_babybear.rs:155-166), so every component column
+    must equal the oracle's base-field (u64-limb) transform of that component; the 2^24 run goes through the three-pass
+    plan with lgV = 2, which the small sizes never reach."""
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()["babybear_ext4"]
+    _, base_oid = util.field_pairs()["babybear_u64"]
+    L = 24
+    a = util.rand_elems("babybear_ext4", 1 << L, 4242)
+    with ThreadPoolExecutor(4) as ex:
+        futs = [ex.submit(O.evaluate_fft, base_oid, np.ascontiguousarray(a[:, k])) for k in range(4)]
+        t_in = torch.from_numpy(a.view(np.int64)).cuda()
+        t_out = torch.empty_like(t_in)
+        fft.ntt_device(fld, t_in, t_out, L)
+        torch.cuda.synchronize()
+        got = t_out.cpu().numpy().view(np.uint64)
+        for k in range(4):
+            assert np.array_equal(got[:, k], np.asarray(futs[k].result()).reshape(-1)), f"component {k}"
+    fft.ntt_device(fld, t_out, t_out, L, inverse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t_out, t_in)
+
+
 @pytest.mark.parametrize("L", [20, 22])
 def test_msm_skewed_scalar_distribution_matches_oracle(L):
     # A prover's witness is not uniform: mostly 0 / 1 / small values, some repeated constants.  Window 0 then has keys
