@@ -38,6 +38,12 @@ def main():
                 fft.ntt_device(fld, x, y, L, batch=B)
                 fft.ntt_device(fld, y, y, L, inverse=True, batch=B)
             torch.cuda.synchronize()
+        # BASELINE config 4 as the LDE it is: 2^22 coefficients per column -> 2^24 evaluations on a coset (lw_hip_ntt_lde_device)
+        x = t(rng.integers(0, P_BB, size=B << (L - 2), dtype=np.uint32)); y = torch.empty(B << L, dtype=torch.int32, device="cuda")
+        off = np.array([268435454 * 3 % P_BB], dtype=np.uint32)
+        for _ in range(reps):
+            fft.lde_device(fft.Babybear31PrimeFieldU32, x, L - 2, y, L, batch=B, offset=off)
+        torch.cuda.synchronize()
         a = rng.integers(0, P_BB, size=(1 << L, 4), dtype=np.uint64)
         x = t(a); y = torch.empty_like(x)
         for _ in range(reps):
@@ -82,6 +88,15 @@ def main():
         l, r, o = elems256(g, 62), elems256(g, 62), elems256(g, 62)
         for _ in range(reps):
             groth16.calculate_h_coefficients(l, r, o, g)
+        # the device-resident forms: one FRI layer with everything in HBM, the Groth16 quotient at 2^20 gates
+        t_co = t(coeffs)
+        for _ in range(reps):
+            merkle.fri_layer_device(fft.Stark252PrimeField, t_co, 1 << 20, one, one, 1 << 21)
+        g = 1 << 20
+        tl, tr, to = (t(elems256(g, 62)) for _ in range(3))
+        for _ in range(reps):
+            groth16.calculate_h_coefficients_device(tl, tr, to, g, g)
+        torch.cuda.synchronize()
     print("done")
 
 
