@@ -561,6 +561,41 @@ int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const
     if (en.rc) return en.rc;
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     RcclTransport tp;
+    // LW_HIP_MSM_SHARD=partials (A/B on real hardware): the first form of SURVEY 8(e) — every rank runs the WHOLE Pippenger
+    // on its shard and one partial sum per rank is all-gathered.  No bucket exchange (W x 2^(c-1) points per rank: 654 MB
+    // for BN254 G1 at c = 20, ~1.7 ms on seven xGMI links by estimate) but the full ~2.5-4.7 ms of running sums on every
+    // rank; the bucket-slice form saves 1.1 ms of them per rank at G = 8 (profiles/r03_msm_sharded_reduce.txt).  Which one
+    // wins is a question for an 8-GPU node; the default is the form the north star names.
+    static const bool partials = [] { const char *e = tuning_env("LW_HIP_MSM_SHARD"); return e && strcmp(e, "partials") == 0; }();
+    if (partials) {
+        Context &c = en.c;
+        const int G = g_comm.nranks;
+        // payload per rank: [status (16-byte header: the point keeps the alignment its stores assume) | partial sum]; the
+        // local outcome travels WITH the point, so a failing rank still enters the collective and all return together
+        constexpr size_t HDR = 16;
+        const size_t slot = HDR + pb;
+        std::vector<uint4> mine_v((slot + 15) / 16), all_v((slot * G + 15) / 16), pts_v((pb * G + 15) / 16);
+        char *mine = (char *)mine_v.data(), *all = (char *)all_v.data(), *pts = (char *)pts_v.data();
+        memset(mine, 0, slot);
+        const int local_rc = msm_device(c, curve, d_scalars, d_points, n_local, mine + HDR, en.stream, 0, 0);
+        const int64_t st = local_rc;
+        memcpy(mine, &st, 8);
+        if (local_rc) memset(mine + HDR, 0, pb);
+        if (c.shard_c.ensure(slot * (G + 1))) return LW_ERR_ALLOC;
+        char *d_send = (char *)c.shard_c.p, *d_recv = d_send + slot;
+        LW_HIP_CHECK(hipMemcpyAsync(d_send, mine, slot, hipMemcpyHostToDevice, en.stream), LW_ERR_LAUNCH);
+        LW_NCCL_CHECK(g_rccl.AllGather(d_send, d_recv, slot, ncclChar, g_comm.comm, en.stream));
+        LW_HIP_CHECK(hipMemcpyAsync(all, d_recv, slot * G, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
+        if (local_rc) return local_rc;
+        for (int g = 0; g < G; g++) {
+            int64_t sg = 0;
+            memcpy(&sg, all + slot * g, 8);
+            if (sg) { set_error("rank %d failed its local MSM (status %lld)", g, (long long)sg); return LW_ERR_COMM; }
+            memcpy(pts + pb * g, all + slot * g + HDR, pb);
+        }
+        return msm_sum_points_host(curve, pts, (size_t)G, out_point_host);
+    }
     const uint64_t *sc[1] = {d_scalars};
     const void *pt[1] = {d_points};
     const size_t nn[1] = {n_local};
