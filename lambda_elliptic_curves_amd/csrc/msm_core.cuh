@@ -335,15 +335,21 @@ struct MsmRunner {
     // SRS preparation (lw_hip_srs_create*): n projective rows -> n affine pairs
     int normalize(const void *d_in, size_t n, void *d_out) {
         if (!n) return LW_OK;
-        if (c.msm_prefix.ensure(n * C::B::BYTES)) return LW_ERR_ALLOC;
-        hipEvent_t pe = c.prof_begin(stream);
+        hipEvent_t pe = nullptr;
         // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
         // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
         static const uint32_t chk_env = [] { const char *e = tuning_env("LW_HIP_MSM_CHK"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning only
         const uint32_t chk = chk_env ? std::min(std::max(chk_env, 1u), 1024u) : (n >= ((size_t)1 << 22) ? 128 : 32);
         const uint64_t items = (n + chk - 1) / chk;
-        hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3((uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
-                           stream, d_in, (uint64_t)n, chk, d_out, c.msm_prefix.p);
+        const uint32_t blocks = (uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS);
+        if (c.msm_prefix.ensure(n * C::B::BYTES)) return LW_ERR_ALLOC;   // running products, one element per point
+        pe = c.prof_begin(stream);
+        // (Measured and dropped, profiles/r03_ab_msm_norm.txt: the two sweeps and the inversions as three kernels — standalone
+        // 2.83 ms either way at 2^24, inside the MSM 2^22 14.7 -> 16.3-17.0 ms, because the inversions alone are a short grid of
+        // long dependent chains (85 product-equivalents each) that this kernel hides behind the other waves' memory phases;
+        // and the same in phases of 2^20 points so that the back sweep re-reads rows from the Infinity Cache: 21.6 ms, one
+        // exposed inversion latency per phase.)
+        hipLaunchKernelGGL((msm_to_affine_kernel<C>), dim3(blocks), dim3(MSM_THREADS), 0, stream, d_in, (uint64_t)n, chk, d_out, c.msm_prefix.p);
         c.prof_end("msm_to_affine_kernel", pe, stream);
         LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         return LW_OK;
