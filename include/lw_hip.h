@@ -110,10 +110,19 @@ typedef struct {
  *
  * Stream contract of the *_device entry points: work is enqueued on `hip_stream` and the call returns without waiting
  * for it, except where a result is handed back through a host pointer (the MSM's out_point_host, out_root): those
- * synchronise the stream before returning.  The library's scratch, tables and workspaces are shared by all calls; a
- * call on a different stream than the previous one first waits (hipStreamWaitEvent) for the previous call's work, so
- * calls may be issued from any stream or thread in any order.  Host-side the calls are serialised by one lock
- * (callers that want column parallelism pass `batch`, not threads). */
+ * synchronise the stream before returning.
+ *
+ * Threads: the library keeps LW_LANES (4) independent sets of scratch, staging buffers, workspaces and side streams
+ * ("lanes", csrc/context.h).  A call takes the first lane that is free, so calls from different host threads — the
+ * reference's rayon loop over columns (provers/stark/src/trace.rs:186-190), an NTT caller beside an MSM caller — run
+ * concurrently: one caller's download overlaps another's upload and kernels (host-buffer entry points run on their lane's
+ * own stream).  More concurrent callers than lanes wait for a lane.  A single-threaded caller always gets lane 0 and sees
+ * a one-context library; lanes allocate lazily, so memory grows only with the concurrency actually used.  Within a lane,
+ * a call on a different stream than the lane's previous one first waits (hipStreamWaitEvent) for that call's work, so
+ * calls may be issued from any stream or thread in any order.  The twiddle tables are shared by all lanes and rebuilt,
+ * when a larger transform arrives, with every other call out of the library.  The multi-GPU entry points (one
+ * communicator per process) always run on lane 0.  Callers that want column parallelism inside ONE call still pass
+ * `batch`. */
 int lw_hip_init(const int *device_ids, int n_devices);
 void lw_hip_shutdown(void);
 int lw_hip_device_count(void);

@@ -66,9 +66,13 @@ void Context::prof_end(const char *name, hipEvent_t e0, hipStream_t s) {
     spans.push_back(ProfSpan{name, e0, e1});
 }
 
-Context &ctx() {
-    static Context c;
-    return c;
+SharedState &shared_state() {
+    static SharedState s;
+    return s;
+}
+Context &lane(int i) {
+    static Context lanes[LW_LANES];
+    return lanes[i];
 }
 
 const char *tuning_env(const char *name) {
@@ -79,7 +83,24 @@ const char *tuning_env(const char *name) {
 void ntt_set_max_pass_stages(uint32_t r);
 void ntt_set_debug(uint32_t d);
 
-static int init_locked(Context &c, const int *device_ids, int n_devices) {
+void host_pool_release_all();
+void comm_release(Context &c);   // comm.hip
+// every cached device object of every lane and the shared tables (shutdown / device change); SharedState::rw held unique
+static void release_everything() {
+    (void)hipDeviceSynchronize();
+    comm_release(lane(0));
+    host_pool_release_all();
+    for (int i = 0; i < LW_LANES; i++) lane(i).release_all();
+    SharedState &sh = shared_state();
+    for (int f = 0; f < 3; f++)
+        for (int d = 0; d < 2; d++) {
+            sh.tw[f][d].buf.release();
+            sh.tw[f][d].valid = false;
+        }
+}
+// SharedState::rw held unique
+static int init_locked(const int *device_ids, int n_devices) {
+    SharedState &sh = shared_state();
 #ifdef LW_HIP_ABLATION
     if (const char *e = tuning_env("LW_HIP_NTT_DBG")) ntt_set_debug((uint32_t)atoi(e));   // wrong results, timing only
 #endif
@@ -112,28 +133,21 @@ static int init_locked(Context &c, const int *device_ids, int n_devices) {
         set_error("device %d is %s; this library ships gfx950 code objects only", dev, prop.gcnArchName);
         return LW_ERR_NO_DEVICE;
     }
-    if (c.initialised && c.device != dev) {   // every cached table / workspace lives on the old device
-        (void)hipSetDevice(c.device);
-        c.release_all();
+    if (sh.initialised && sh.device != dev) {   // every cached table / workspace lives on the old device
+        (void)hipSetDevice(sh.device);
+        release_everything();
         (void)hipSetDevice(dev);
     }
-    c.device = dev;
-    c.initialised = true;
+    sh.device = dev;
+    sh.initialised = true;
+    for (int i = 0; i < LW_LANES; i++) {
+        lane(i).device = dev;
+        lane(i).initialised = true;
+    }
     return LW_OK;
 }
 
-void comm_release(Context &c);   // comm.hip
-
-void host_pool_release_all();
 void Context::release_all() {
-    (void)hipDeviceSynchronize();
-    host_pool_release_all();
-    comm_release(*this);
-    for (int f = 0; f < 3; f++)
-        for (int d = 0; d < 2; d++) {
-            tw[f][d].buf.release();
-            tw[f][d].valid = false;
-        }
     scratch.release();
     small.release();
     for (int i = 0; i < 3; i++) {
@@ -152,6 +166,7 @@ void Context::release_all() {
     shard_c.release();
     if (aux_stream) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; }
     if (aux_hi) { (void)hipStreamDestroy(aux_hi); aux_hi = nullptr; }
+    if (io_stream) { (void)hipStreamDestroy(io_stream); io_stream = nullptr; }
     if (aux_fork) { (void)hipEventDestroy(aux_fork); aux_fork = nullptr; }
     if (aux_join) { (void)hipEventDestroy(aux_join); aux_join = nullptr; }
     if (order_event) { (void)hipEventDestroy(order_event); order_event = nullptr; }
@@ -170,9 +185,34 @@ void Context::release_all() {
     timings.twiddle_bytes = timings.scratch_bytes = 0;
 }
 
-Entry::Entry(void *hip_stream) : c(ctx()), lock(c.mu), stream((hipStream_t)hip_stream) {
-    rc = ensure_init();
-    if (rc) return;
+// first free lane; when all are busy, wait for one (round robin, so that waiters spread over the lanes)
+static Context &pick_lane(std::unique_lock<std::mutex> &lk, bool lane0) {
+    if (lane0) {
+        lk = std::unique_lock<std::mutex>(lane(0).mu);
+        return lane(0);
+    }
+    for (int i = 0; i < LW_LANES; i++) {
+        lk = std::unique_lock<std::mutex>(lane(i).mu, std::try_to_lock);
+        if (lk.owns_lock()) return lane(i);
+    }
+    static std::atomic<unsigned> rr{0};
+    const int i = (int)(rr.fetch_add(1) % LW_LANES);
+    lk = std::unique_lock<std::mutex>(lane(i).mu);
+    return lane(i);
+}
+static std::shared_lock<std::shared_mutex> enter_shared() {
+    for (int attempt = 0;; attempt++) {   // lazily initialised; a shutdown may slip in between the two locks, hence the loop
+        const int rc = ensure_init();
+        std::shared_lock<std::shared_mutex> sl(shared_state().rw);
+        if (shared_state().initialised || rc != LW_OK || attempt > 3) return sl;
+    }
+}
+Entry::Entry(void *hip_stream, bool lane0) : c(pick_lane(lock, lane0)), shared(enter_shared()), stream((hipStream_t)hip_stream) {
+    if (!shared_state().initialised) {
+        rc = LW_ERR_NO_DEVICE;   // ensure_init() left the reason in the thread's error message
+        return;
+    }
+    c.call_lock = &shared;
     if (hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
     if (prev_device != c.device && hipSetDevice(c.device) != hipSuccess) {
         set_error("hipSetDevice(%d) failed", c.device);
@@ -185,6 +225,20 @@ Entry::Entry(void *hip_stream) : c(ctx()), lock(c.mu), stream((hipStream_t)hip_s
         rc = LW_ERR_LAUNCH;
     }
 }
+hipStream_t Entry::use_lane_stream() {
+    if (!c.io_stream && hipStreamCreateWithFlags(&c.io_stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("cannot create the lane's stream");
+        rc = LW_ERR_LAUNCH;
+        return nullptr;
+    }
+    if (c.have_last && c.last_stream != c.io_stream && c.order_event && hipStreamWaitEvent(c.io_stream, c.order_event, 0) != hipSuccess) {
+        set_error("hipStreamWaitEvent on the previous call's stream failed");
+        rc = LW_ERR_LAUNCH;
+        return nullptr;
+    }
+    stream = c.io_stream;
+    return stream;
+}
 Entry::~Entry() {
     if (rc == LW_OK || c.initialised) {
         if (!c.order_event && c.initialised) (void)hipEventCreateWithFlags(&c.order_event, hipEventDisableTiming);
@@ -193,13 +247,19 @@ Entry::~Entry() {
             c.have_last = true;
         }
     }
+    c.call_lock = nullptr;
     if (prev_device >= 0 && prev_device != c.device) (void)hipSetDevice(prev_device);
 }
 
 int ensure_init() {
-    Context &c = ctx();
-    if (c.initialised) return LW_OK;
-    return init_locked(c, nullptr, 0);
+    SharedState &sh = shared_state();
+    {
+        std::shared_lock<std::shared_mutex> sl(sh.rw);
+        if (sh.initialised) return LW_OK;
+    }
+    std::unique_lock<std::shared_mutex> ul(sh.rw);
+    if (sh.initialised) return LW_OK;
+    return init_locked(nullptr, 0);
 }
 
 // defined in ntt256.hip / ntt_bb.hip / msm.hip
@@ -394,15 +454,17 @@ struct Prefault {
         }
     }
     // dst = base + off: device -> host, chunk by chunk behind the populate front (one plain copy when nothing is being populated)
-    int copy_back(const void *d_src, size_t nbytes) {
+    int copy_back(const void *d_src, size_t nbytes, hipStream_t s) {
         if (!active) {
-            LW_HIP_CHECK(hipMemcpy(base, d_src, nbytes, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipMemcpyAsync(base, d_src, nbytes, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
             return LW_OK;
         }
         for (size_t k = 0; k < nchunks; k++) {
             while (!done[k].load(std::memory_order_acquire)) std::this_thread::yield();
             const size_t off = k * CHUNK, len = off + CHUNK < nbytes ? CHUNK : nbytes - off;
-            LW_HIP_CHECK(hipMemcpy(base + off, (const char *)d_src + off, len, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipMemcpyAsync(base + off, (const char *)d_src + off, len, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
         }
         return LW_OK;
     }
@@ -422,21 +484,21 @@ static bool elem_is_zero(const unsigned char *p, size_t eb);
 extern "C" {
 
 int lw_hip_init(const int *device_ids, int n_devices) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    return init_locked(c, device_ids, n_devices);
+    std::unique_lock<std::shared_mutex> g(shared_state().rw);   // no call is running
+    return init_locked(device_ids, n_devices);
 }
 
 void lw_hip_shutdown(void) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    if (!c.initialised) return;
+    SharedState &sh = shared_state();
+    std::unique_lock<std::shared_mutex> g(sh.rw);
+    if (!sh.initialised) return;
     int prev = -1;
     (void)hipGetDevice(&prev);
-    (void)hipSetDevice(c.device);
-    c.release_all();
+    (void)hipSetDevice(sh.device);
+    release_everything();
     if (prev >= 0) (void)hipSetDevice(prev);
-    c.initialised = false;
+    sh.initialised = false;
+    for (int i = 0; i < LW_LANES; i++) lane(i).initialised = false;
 }
 
 int lw_hip_device_count(void) {
@@ -447,54 +509,84 @@ int lw_hip_device_count(void) {
 
 const char *lw_hip_last_error(void) { return g_last_error.c_str(); }
 
-int lw_hip_profile_begin(void) {
-    Entry en(nullptr);
-    if (en.rc) return en.rc;
-    Context &c = en.c;
-    int rc = LW_OK;
-    for (auto &sp : c.spans) {   // a begin without an end: recycle the pending events
-        c.event_pool.push_back(sp.e0);
-        c.event_pool.push_back(sp.e1);
+// Exclusive access to every lane with the context's device bound: profile begin / end, timings.
+struct AllLanes {
+    std::unique_lock<std::shared_mutex> g;
+    int rc = LW_OK, prev = -1;
+    AllLanes() {
+        rc = ensure_init();
+        g = std::unique_lock<std::shared_mutex>(shared_state().rw);
+        if (!rc && !shared_state().initialised) rc = LW_ERR_NO_DEVICE;
+        if (rc) return;
+        (void)hipGetDevice(&prev);
+        if (prev != shared_state().device) (void)hipSetDevice(shared_state().device);
     }
-    c.spans.clear();
-    c.profiling = true;
+    ~AllLanes() {
+        if (!rc && prev >= 0 && prev != shared_state().device) (void)hipSetDevice(prev);
+    }
+};
+
+int lw_hip_profile_begin(void) {
+    AllLanes all;
+    if (all.rc) return all.rc;
+    for (int i = 0; i < LW_LANES; i++) {
+        Context &c = lane(i);
+        for (auto &sp : c.spans) {   // a begin without an end: recycle the pending events
+            c.event_pool.push_back(sp.e0);
+            c.event_pool.push_back(sp.e1);
+        }
+        c.spans.clear();
+        c.profiling = true;
+    }
     return LW_OK;
 }
 
 int lw_hip_profile_end(lw_profile_t *out) {
     if (!out) return LW_ERR_BAD_ARG;
-    Entry en(nullptr);
-    if (en.rc) return en.rc;
-    Context &c = en.c;
-    c.profiling = false;
+    AllLanes all;
+    if (all.rc) return all.rc;
     memset(out, 0, sizeof(*out));
     LW_HIP_CHECK(hipDeviceSynchronize(), LW_ERR_LAUNCH);
-    for (auto &sp : c.spans) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, sp.e0, sp.e1);
-        int idx = -1;
-        for (int i = 0; i < out->n; i++)
-            if (strcmp(out->k[i].name, sp.name) == 0) idx = i;
-        if (idx < 0 && out->n < (int)(sizeof(out->k) / sizeof(out->k[0]))) {
-            idx = out->n++;
-            strncpy(out->k[idx].name, sp.name, sizeof(out->k[idx].name) - 1);
+    for (int i = 0; i < LW_LANES; i++) {
+        Context &c = lane(i);
+        c.profiling = false;
+        for (auto &sp : c.spans) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, sp.e0, sp.e1);
+            int idx = -1;
+            for (int k = 0; k < out->n; k++)
+                if (strcmp(out->k[k].name, sp.name) == 0) idx = k;
+            if (idx < 0 && out->n < (int)(sizeof(out->k) / sizeof(out->k[0]))) {
+                idx = out->n++;
+                strncpy(out->k[idx].name, sp.name, sizeof(out->k[idx].name) - 1);
+            }
+            if (idx >= 0) {
+                out->k[idx].launches++;
+                out->k[idx].total_ms += ms;
+            }
+            c.event_pool.push_back(sp.e0);
+            c.event_pool.push_back(sp.e1);
         }
-        if (idx >= 0) {
-            out->k[idx].launches++;
-            out->k[idx].total_ms += ms;
-        }
-        c.event_pool.push_back(sp.e0);
-        c.event_pool.push_back(sp.e1);
+        c.spans.clear();
     }
-    c.spans.clear();
     return LW_OK;
 }
 
 int lw_hip_get_timings(lw_timings_t *out) {
     if (!out) return LW_ERR_BAD_ARG;
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
-    *out = c.timings;
+    std::unique_lock<std::shared_mutex> g(shared_state().rw);
+    lw_timings_t t = {};
+    for (int i = 0; i < LW_LANES; i++) {   // calls summed over the lanes; "last" = the longest of the lanes' last calls
+        const lw_timings_t &l = lane(i).timings;
+        t.ntt_calls += l.ntt_calls;
+        t.msm_calls += l.msm_calls;
+        t.last_ntt_ms = l.last_ntt_ms > t.last_ntt_ms ? l.last_ntt_ms : t.last_ntt_ms;
+        t.last_msm_ms = l.last_msm_ms > t.last_msm_ms ? l.last_msm_ms : t.last_msm_ms;
+        t.scratch_bytes += lane(i).scratch.bytes;
+    }
+    for (int f = 0; f < 3; f++)
+        for (int d = 0; d < 2; d++) t.twiddle_bytes += shared_state().tw[f][d].valid ? shared_state().tw[f][d].buf.bytes : 0;
+    *out = t;
     return LW_OK;
 }
 
@@ -706,18 +798,21 @@ int lw_hip_ntt(lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *i
     if (stride < n) { set_error("batch stride %zu < transform length", stride); return LW_ERR_BAD_ARG; }
     const size_t span = ((size_t)(batch - 1) * stride + n) * eb;
     if (c.host_io_a.ensure(span) || c.host_io_b.ensure(span)) return LW_ERR_ALLOC;
+    hipStream_t io = en.use_lane_stream();
+    if (!io) return en.rc;
     Prefault pf;
     pf.start(out, span, in, span);
-    LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, in, span, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
-    rc = ntt_device_locked(c, field, layout, dir, c.host_io_a.p, c.host_io_b.p, log2n, batch, stride, coset_offset_or_null, 0);
+    LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, in, span, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
+    rc = ntt_device_locked(c, field, layout, dir, c.host_io_a.p, c.host_io_b.p, log2n, batch, stride, coset_offset_or_null, io);
     if (rc) return rc;
-    LW_HIP_CHECK(hipStreamSynchronize(0), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(io), LW_ERR_LAUNCH);
     if (stride == n) {
-        rc = pf.copy_back(c.host_io_b.p, span);
+        rc = pf.copy_back(c.host_io_b.p, span, io);
         if (rc) return rc;
     } else {   // leave the gaps between strided transforms untouched
         pf.join();
-        LW_HIP_CHECK(hipMemcpy2D(out, stride * eb, c.host_io_b.p, stride * eb, n * eb, batch, hipMemcpyDeviceToHost), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipMemcpy2DAsync(out, stride * eb, c.host_io_b.p, stride * eb, n * eb, batch, hipMemcpyDeviceToHost, io), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize(io), LW_ERR_LAUNCH);
     }
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.ntt_calls++;
@@ -773,15 +868,17 @@ int lw_polynomial_evaluate_fft(lw_field_t field, lw_layout_t layout, const void 
     const bool lde = in_log2 >= 1 && in_log2 < log2n;
     const size_t up = lde ? block : len;
     if (c.host_io_a.ensure(up * eb) || c.host_io_b.ensure(len * eb)) return LW_ERR_ALLOC;
+    hipStream_t io = en.use_lane_stream();
+    if (!io) return en.rc;
     Prefault pf;
     pf.start(out, len * eb, coeffs, n_coeffs * eb);
-    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, up * eb, 0), LW_ERR_LAUNCH);
-    LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, coeffs, clen * eb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
-    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, 0,
+    LW_HIP_CHECK(hipMemsetAsync(c.host_io_a.p, 0, up * eb, io), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, coeffs, clen * eb, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
+    rc = ntt_device_locked(c, field, layout, LW_DIR_FORWARD, c.host_io_a.p, c.host_io_b.p, log2n, 1, len, offset_or_null, io,
                            lde ? in_log2 : log2n);
     if (rc) return rc;
-    LW_HIP_CHECK(hipStreamSynchronize(0), LW_ERR_LAUNCH);
-    rc = pf.copy_back(c.host_io_b.p, len * eb);
+    LW_HIP_CHECK(hipStreamSynchronize(io), LW_ERR_LAUNCH);
+    rc = pf.copy_back(c.host_io_b.p, len * eb, io);
     if (rc) return rc;
     c.timings.last_ntt_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.ntt_calls++;
@@ -1055,10 +1152,14 @@ static int msm_host_entry(lw_curve_t curve, const uint64_t *scalars, size_t n_sc
     if (n) {
         if (!scalars || !points) { set_error("null buffer"); return LW_ERR_BAD_ARG; }
         if (c.host_io_a.ensure(n * 32) || c.host_io_b.ensure(n * pb)) return LW_ERR_ALLOC;
-        LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
-        LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     }
-    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, 0, mont, 0);
+    hipStream_t io = en.use_lane_stream();
+    if (!io) return en.rc;
+    if (n) {
+        LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipMemcpyAsync(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
+    }
+    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, io, mont, 0);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;
@@ -1091,8 +1192,7 @@ struct lw_srs {
 };
 extern "C" {
 
-static int srs_build(lw_curve_t curve, const void *d_points, size_t n, hipStream_t stream, lw_srs_t **out_srs) {
-    Context &c = ctx();
+static int srs_build(Context &c, lw_curve_t curve, const void *d_points, size_t n, hipStream_t stream, lw_srs_t **out_srs) {
     const size_t pb = lw_hip_curve_point_bytes(curve);
     lw_srs *h = new (std::nothrow) lw_srs{curve, n, {}};
     if (!h) return LW_ERR_ALLOC;
@@ -1126,7 +1226,7 @@ int lw_hip_srs_create_device(lw_curve_t curve, const void *d_points, size_t n_po
     if (en.rc) return en.rc;
     Context &c = en.c;
     int rc = LW_OK;
-    return srs_build(curve, d_points, n_points, (hipStream_t)hip_stream, out_srs);
+    return srs_build(c, curve, d_points, n_points, (hipStream_t)hip_stream, out_srs);
 }
 int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_srs_t **out_srs) {
     const size_t pb = lw_hip_curve_point_bytes(curve);
@@ -1139,7 +1239,7 @@ int lw_hip_srs_create(lw_curve_t curve, const void *points, size_t n_points, lw_
         if (c.host_io_b.ensure(n_points * pb)) return LW_ERR_ALLOC;
         LW_HIP_CHECK(hipMemcpy(c.host_io_b.p, points, n_points * pb, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
     }
-    return srs_build(curve, c.host_io_b.p, n_points, 0, out_srs);
+    return srs_build(c, curve, c.host_io_b.p, n_points, 0, out_srs);
 }
 int lw_hip_srs_destroy(lw_srs_t *srs) {
     if (!srs) return LW_OK;
@@ -1162,9 +1262,13 @@ static int msm_srs_entry(const lw_srs_t *srs, const uint64_t *scalars, size_t n,
     int rc = LW_OK;
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t *d_scalars = scalars;
+    if (host_scalars) {   // host-buffer form: on the lane's own stream
+        stream = en.use_lane_stream();
+        if (!stream) return en.rc;
+    }
     if (host_scalars && n) {
         if (c.host_io_a.ensure(n * 32)) return LW_ERR_ALLOC;
-        LW_HIP_CHECK(hipMemcpy(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice, stream), LW_ERR_LAUNCH);
         d_scalars = (const uint64_t *)c.host_io_a.p;
     }
     // the shifted copies serve calls that use a good part of the set (KZG commits of shorter polynomials take a prefix:

@@ -119,6 +119,7 @@ void comm_release(Context &) {
 // all_to_all: for every local rank g, batch b and peer h, chunk (b, h) of g's send buffer becomes chunk (b, g) of h's
 // receive buffer.  Chunks are `chunk_bytes` long; consecutive b are `bstride_bytes` apart.
 struct Transport {
+    Context *cx = nullptr;       // the running call's lane (lane 0: the communicator's buffers live there)
     int G = 1;
     int first = 0, nlocal = 1;   // ranks [first, first + nlocal) live in this process
     virtual int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
@@ -132,7 +133,7 @@ struct Transport {
 };
 
 struct RcclTransport : Transport {
-    RcclTransport() { G = g_comm.nranks; first = g_comm.rank; nlocal = 1; }
+    explicit RcclTransport(Context &c) { cx = &c; G = g_comm.nranks; first = g_comm.rank; nlocal = 1; }
     int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
                    hipStream_t s) override {
         LW_NCCL_CHECK(g_rccl.GroupStart());
@@ -154,7 +155,7 @@ struct RcclTransport : Transport {
         return LW_OK;
     }
     int agree(int local_status, hipStream_t s) override {
-        Context &c = ctx();
+        Context &c = *cx;
         if (c.small.ensure(8 * (size_t)(G + 1))) return LW_ERR_ALLOC;   // (an allocation of 72 bytes: if this fails nothing works)
         int64_t mine = local_status, all[9] = {0};
         int64_t *d = (int64_t *)c.small.p;
@@ -170,7 +171,7 @@ struct RcclTransport : Transport {
 };
 
 struct SimTransport : Transport {   // G virtual ranks on one device
-    explicit SimTransport(int g) { G = g; first = 0; nlocal = g; }
+    SimTransport(Context &c, int g) { cx = &c; G = g; first = 0; nlocal = g; }
     int all_to_all(const char *const *send, char *const *recv, size_t chunk_bytes, uint32_t batch, size_t bstride_bytes,
                    hipStream_t s) override {
         for (int g = 0; g < G; g++)
@@ -455,7 +456,7 @@ extern "C" {
 
 int lw_hip_comm_unique_id(uint8_t *out_id) {
     if (!out_id) { set_error("null argument"); return LW_ERR_BAD_ARG; }
-    Entry en(nullptr);
+    Entry en(nullptr, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     int rc = rccl_load();
     if (rc) return rc;
@@ -469,7 +470,7 @@ int lw_hip_comm_unique_id(uint8_t *out_id) {
 int lw_hip_comm_init(const uint8_t *unique_id, int rank, int nranks) {
     if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) { set_error("bad communicator arguments (rank %d of %d)", rank, nranks); return LW_ERR_BAD_ARG; }
     if (nranks & (nranks - 1) || nranks > 8) { set_error("communicator size %d: the sharded paths take 1, 2, 4 or 8 ranks (one node)", nranks); return LW_ERR_BAD_ARG; }
-    Entry en(nullptr);
+    Entry en(nullptr, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     int rc = rccl_load();
     if (rc) return rc;
@@ -485,7 +486,7 @@ int lw_hip_comm_init(const uint8_t *unique_id, int rank, int nranks) {
 }
 
 int lw_hip_comm_shutdown(void) {
-    Entry en(nullptr);
+    Entry en(nullptr, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     (void)hipDeviceSynchronize();
     comm_release(en.c);
@@ -493,8 +494,7 @@ int lw_hip_comm_shutdown(void) {
 }
 
 int lw_hip_comm_info(int *rank, int *nranks) {
-    Context &c = ctx();
-    std::lock_guard<std::mutex> g(c.mu);
+    std::lock_guard<std::mutex> g(lane(0).mu);   // the communicator lives with lane 0
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     if (rank) *rank = g_comm.rank;
     if (nranks) *nranks = g_comm.nranks;
@@ -505,11 +505,11 @@ int lw_hip_ntt_sharded_device(lw_field_t field, lw_layout_t layout, lw_dir_t dir
                               uint32_t log2n_total, uint32_t batch, int natural_output, void *hip_stream) {
     int rc = check_sharded_args(field, layout, dir, d_in_local, d_out_local, log2n_total);
     if (rc) return rc;
-    Entry en(hip_stream);
+    Entry en(hip_stream, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     if (batch == 0) return LW_OK;
-    RcclTransport tp;
+    RcclTransport tp(en.c);
     uint32_t lg = 0;
     while ((1 << lg) < tp.G) lg++;
     if (log2n_total < lg) { set_error("2^%u elements over %d ranks", log2n_total, tp.G); return LW_ERR_BAD_ARG; }
@@ -526,10 +526,10 @@ static int sharded_selftest(lw_field_t field, lw_layout_t layout, lw_dir_t dir, 
     if (rc) return rc;
     if (log2_shards < 1 || log2_shards > 3) { set_error("self-test takes 2, 4 or 8 virtual ranks"); return LW_ERR_BAD_ARG; }
     if (d_in_full == d_out_full) { set_error("self-test needs distinct buffers"); return LW_ERR_BAD_ARG; }
-    Entry en(hip_stream);
+    Entry en(hip_stream, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     if (batch == 0) return LW_OK;
-    SimTransport tp(1 << log2_shards);
+    SimTransport tp(en.c, 1 << log2_shards);
     if (log2n_total < 2 * log2_shards) { set_error("2^%u elements over %d ranks", log2n_total, tp.G); return LW_ERR_BAD_ARG; }
     const size_t eb = lw_hip_field_elem_bytes(field, layout);
     const uint64_t N = 1ull << log2n_total, M = N >> log2_shards;
@@ -557,10 +557,10 @@ int lw_hip_msm_sharded_device(lw_curve_t curve, const uint64_t *d_scalars, const
                               void *hip_stream) {
     const size_t pb = lw_hip_curve_point_bytes(curve);
     if (pb == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
-    Entry en(hip_stream);
+    Entry en(hip_stream, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
-    RcclTransport tp;
+    RcclTransport tp(en.c);
     // LW_HIP_MSM_SHARD=partials (A/B on real hardware): the first form of SURVEY 8(e) — every rank runs the WHOLE Pippenger
     // on its shard and one partial sum per rank is all-gathered.  No bucket exchange (W x 2^(c-1) points per rank: 654 MB
     // for BN254 G1 at c = 20, ~1.7 ms on seven xGMI links by estimate) but the full ~2.5-4.7 ms of running sums on every
@@ -608,9 +608,9 @@ int lw_hip_msm_sharded_selftest_device(lw_curve_t curve, const uint64_t *d_scala
     const size_t pb = lw_hip_curve_point_bytes(curve);
     if (pb == 0 || !out_point_host) { set_error("bad curve or null output"); return LW_ERR_BAD_ARG; }
     if (log2_shards < 1 || log2_shards > 3) { set_error("self-test takes 2, 4 or 8 virtual ranks"); return LW_ERR_BAD_ARG; }
-    Entry en(hip_stream);
+    Entry en(hip_stream, true);   // lane 0: the communicator and its buffers
     if (en.rc) return en.rc;
-    SimTransport tp(1 << log2_shards);
+    SimTransport tp(en.c, 1 << log2_shards);
     std::vector<const uint64_t *> sc(tp.G);
     std::vector<const void *> pt(tp.G);
     std::vector<size_t> nn(tp.G);

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 #include "../../include/lw_hip.h"
@@ -64,6 +65,27 @@ struct ProfSpan {
     hipEvent_t e0, e1;
 };
 
+// State shared by all lanes (below): the twiddle tables (256 MiB per field and direction at 2^24 — not something to keep
+// per lane) and the lock that separates ordinary calls from the operations that touch every lane.
+//   rw held SHARED  by every entry point for the duration of its call (it may hold table pointers, lane buffers);
+//   rw held UNIQUE  by init / shutdown / profile begin + end / timings, and while a twiddle table is rebuilt: then no call is
+//                   running, so the old table can be freed (hipFree also drains the device) and every lane may be touched.
+struct SharedState {
+    std::shared_mutex rw;
+    TwiddleTable tw[3][2];   // [field][dir]
+    bool initialised = false;
+    int device = -1;
+};
+SharedState &shared_state();
+
+// One LANE of the library: everything a call scribbles on (scratch, staging, MSM workspace, side streams, the cross-stream
+// ordering event).  A call takes the first lane whose lock is free, so calls from different host threads — the reference's
+// rayon loop over columns, provers/stark/src/trace.rs:186-190, or an NTT caller beside an MSM caller — run CONCURRENTLY on
+// different lanes (one caller's download overlaps the other's upload and kernels); a single-threaded caller always gets
+// lane 0 and sees exactly the behaviour of a one-context library.  Lanes allocate lazily: memory grows with the
+// concurrency actually used.
+constexpr int LW_LANES = 4;
+
 struct Context {
     bool profiling = false;
     std::vector<ProfSpan> spans;
@@ -72,10 +94,11 @@ struct Context {
     hipEvent_t prof_begin(hipStream_t s);
     void prof_end(const char *name, hipEvent_t e0, hipStream_t s);
 
-    bool initialised = false;
+    bool initialised = false;   // mirrors of SharedState (set for every lane by init)
     int device = -1;
     std::mutex mu;
-    TwiddleTable tw[3][2];   // [field][dir]
+    TwiddleTable (&tw)[3][2] = shared_state().tw;   // shared by all lanes; rebuilt only under SharedState::rw held unique
+    std::shared_lock<std::shared_mutex> *call_lock = nullptr;   // the running call's shared hold on SharedState::rw (Entry)
     DeviceBuf bb_coset;      // two-level power tables of the current BabyBear coset offset (rebuilt per call: 8192 exponentiations)
     DeviceBuf scratch;
     DeviceBuf small;         // staging for small power tables
@@ -93,6 +116,7 @@ struct Context {
     hipStream_t aux_hi = nullptr;       // high-priority side stream: short kernels that must get CU slots UNDER a long-running kernel of the caller's stream
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     DeviceBuf host_io_a, host_io_b;   // device staging for the host-buffer entry points
+    hipStream_t io_stream = nullptr;  // ... and the stream they run on
     DeviceBuf pipe_tmp;               // intermediates of the device-resident pipelines (FRI layer evaluation, Groth16 cosets)
     lw_timings_t timings = {};
     // Cross-stream ordering of the context-owned buffers (scratch, tables, staging, MSM workspace): every entry point
@@ -111,17 +135,38 @@ struct Context {
 // Held by every extern "C" entry point for its whole duration: context lock, lazy init, device binding (the HIP
 // current device is per thread) and the cross-stream ordering above.
 struct Entry {
+    // Lock order: the lane first, SharedState::rw second.  (A caller waiting for a lane must not hold rw: the lane's owner may be
+    // waiting to upgrade its own hold to exclusive, which needs every shared holder out.)
+    std::unique_lock<std::mutex> lock;            // the lane's lock
     Context &c;
-    std::unique_lock<std::mutex> lock;
+    std::shared_lock<std::shared_mutex> shared;   // SharedState::rw, shared
     hipStream_t stream;
     int rc = LW_OK;
     int prev_device = -1;
-    explicit Entry(void *hip_stream);
+    // lane0: the call uses process-wide state that lives with lane 0 (the RCCL communicator and its exchange buffers)
+    explicit Entry(void *hip_stream, bool lane0 = false);
+    // Host-buffer entry points: switch the call to the lane's own (non-blocking) stream instead of the null stream, so that
+    // calls running on different lanes do not serialise on it; returns the stream (nullptr + rc set on failure).
+    hipStream_t use_lane_stream();
     ~Entry();
     Entry(const Entry &) = delete;
 };
+// Upgrade of the running call's hold on SharedState::rw to exclusive for the duration of a scope (twiddle rebuild): releases
+// the shared hold first — other calls drain — and takes it back afterwards.  Re-check the condition after construction.
+struct ExclusiveScope {
+    Context &c;
+    explicit ExclusiveScope(Context &cc) : c(cc) {
+        if (c.call_lock) c.call_lock->unlock();
+        shared_state().rw.lock();
+    }
+    ~ExclusiveScope() {
+        shared_state().rw.unlock();
+        if (c.call_lock) c.call_lock->lock();
+    }
+};
 
-Context &ctx();
+Context &lane(int i);
+inline Context &ctx() { return lane(0); }
 int ensure_init();
 
 }  // namespace lw

@@ -47,6 +47,11 @@ static int ensure_twiddles(Context &c, int field, lw_dir_t dir, uint32_t log2n, 
     TwiddleTable &t = c.tw[field][dir];
     if (t.valid && t.log_n >= log2n) return LW_OK;
     if (log2n < 1) return LW_OK;
+    // The tables are shared by all lanes: (re)building one needs every other call out of the library (the old table is
+    // freed).  The call's shared hold is given up for the scope and taken back afterwards; another lane may have built the
+    // table in between.
+    ExclusiveScope excl(c);
+    if (t.valid && t.log_n >= log2n) return LW_OK;
     // build for at least 2^16 so small transforms never trigger a rebuild storm
     uint32_t L = log2n < 16 ? 16 : log2n;
     if (L > F::TWO_ADICITY) L = log2n;
@@ -68,9 +73,6 @@ static int ensure_twiddles(Context &c, int field, lw_dir_t dir, uint32_t log2n, 
     hi.release();
     t.log_n = L;
     t.valid = true;
-    c.timings.twiddle_bytes = 0;
-    for (int f = 0; f < 3; f++)
-        for (int d = 0; d < 2; d++) c.timings.twiddle_bytes += c.tw[f][d].valid ? c.tw[f][d].buf.bytes : 0;
     return LW_OK;
 }
 

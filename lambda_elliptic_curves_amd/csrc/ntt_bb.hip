@@ -336,6 +336,8 @@ static int bb_ensure_twiddles(Context &c, lw_dir_t dir, uint32_t log2n, hipStrea
     TwiddleTable &t = c.tw[LW_FIELD_BABYBEAR][dir];
     if (t.valid && t.log_n >= log2n) return LW_OK;
     if (log2n < 1) return LW_OK;
+    ExclusiveScope excl(c);   // shared tables: rebuild with every other call out of the library (ntt256.hip ensure_twiddles)
+    if (t.valid && t.log_n >= log2n) return LW_OK;
     uint32_t L = log2n < 16 ? 16 : log2n;
     const uint32_t bits = L - 1;
     const uint64_t count = 1ull << bits;

@@ -144,3 +144,54 @@ def test_pooled_result_buffers():
     assert L_.lib().lw_hip_result_release(junk.ctypes.data_as(C.c_void_p)) == L_.ERR_BAD_ARG
     p = C.c_void_p()
     assert L_.lib().lw_hip_result_acquire(0, C.byref(p)) == L_.ERR_BAD_ARG
+
+
+def test_concurrent_callers_run_on_lanes_and_share_growing_tables():
+    """Calls from different host threads run concurrently on different lanes (csrc/context.h); the twiddle tables are shared
+    and a call that needs a bigger one rebuilds it with every other call out of the library.  Eight threads, each walking
+    sizes that force rebuilds of three tables (forward, inverse, BabyBear) while the others are mid-call, host and device
+    entry points mixed; every result against the oracle."""
+    import threading
+    import torch
+    from lambda_elliptic_curves_amd import _lib, fft
+    from oracle import oracle as O
+    from tests import util
+    _lib.lib().lw_hip_shutdown()              # start from empty tables
+    fs, os_ = util.field_pairs()["stark252"]
+    fb, ob = util.field_pairs()["babybear_u32"]
+    sizes = [6, 17, 12, 18, 9, 19, 16]       # tables are built for >= 2^16: 17, 18, 19 each force a rebuild
+    cases = {}
+    for L in set(sizes):
+        a = util.rand_elems("stark252", 1 << L, 100 + L)
+        b = util.rand_elems("babybear_u32", 1 << L, 200 + L)
+        cases[L] = (a, O.evaluate_fft(os_, a), b, np.asarray(O.evaluate_fft(ob, b)).reshape(-1))
+    errs = []
+
+    def worker(t):
+        try:
+            for k in range(len(sizes)):
+                L = sizes[(k + t) % len(sizes)]
+                a, ea, b, eb = cases[L]
+                if not np.array_equal(fft.ntt(fs, a), ea):
+                    errs.append(f"stark fwd 2^{L} thread {t}")
+                if not np.array_equal(fft.ntt(fs, ea, inverse=True), a):
+                    errs.append(f"stark inv 2^{L} thread {t}")
+                if not np.array_equal(fft.ntt(fb, b), eb):
+                    errs.append(f"babybear 2^{L} thread {t}")
+                if t % 2:
+                    s = torch.cuda.Stream()
+                    ta = torch.from_numpy(a.view(np.int64)).cuda()
+                    to = torch.empty_like(ta)
+                    fft.ntt_device(fs, ta, to, L, stream=s.cuda_stream)
+                    s.synchronize()
+                    if not np.array_equal(to.cpu().numpy().view(np.uint64), ea):
+                        errs.append(f"stark device 2^{L} thread {t}")
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs[:5]
+    t = _lib.Timings()
+    assert _lib.lib().lw_hip_get_timings(C.byref(t)) == 0 and t.ntt_calls >= 8 * len(sizes) * 3
