@@ -269,6 +269,14 @@ int lw_stark_commit_columns(lw_field_t field, const void *columns, uint32_t n_co
 int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems,
                                    uint32_t log2n, int bit_reverse, void *d_nodes, uint8_t *out_root_or_null, void *hip_stream);
 
+/* The same commitment for any layout whose elements have an AsBytes in the reference — in particular the BabyBear columns
+ * of BASELINE config 4 (the STARK LDE): U32MontgomeryBackendPrimeField hashes value().to_be_bytes(), 4 bytes per element
+ * (u32_montgomery_backend_prime_field.rs:258-262), the u64-limb BabyBear its one limb big-endian
+ * (montgomery_backed_prime_fields.rs:367-373).  LW_LAYOUT_EXT4_INTERLEAVED is rejected (no AsBytes in the reference). */
+int lw_stark_commit_columns_layout_device(lw_field_t field, lw_layout_t layout, const void *d_columns, uint32_t n_cols,
+                                          uint64_t col_stride_elems, uint32_t log2n, int bit_reverse, void *d_nodes,
+                                          uint8_t *out_root_or_null, void *hip_stream);
+
 /* One layer of the FRI commit phase (SURVEY 8f "next" #4), the loop body of commit_phase
  * (provers/stark/src/fri/mod.rs:44-58): p' = 2 * fold_polynomial(p, zeta) (fri/fri_functions.rs:7-30), then
  * new_fri_layer(p', coset_offset, domain_size) (fri/mod.rs:115-141): evaluation on the coset, bit-reverse permuted,

@@ -24,7 +24,7 @@ EXPORTS = [
     "lw_hip_gen_twiddles", "lw_hip_gen_powers", "lw_hip_bitrev_permutation", "lw_hip_ntt_lde_device",
     "lw_polynomial_evaluate_fft", "lw_polynomial_interpolate_fft", "lw_hip_msm", "lw_hip_msm_device",
     "lw_hip_msm_fr", "lw_hip_msm_fr_device", "lw_groth16_h_coefficients",
-    "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_fri_layer",
+    "lw_stark_commit_columns", "lw_stark_commit_columns_device", "lw_stark_commit_columns_layout_device", "lw_stark_fri_layer",
     "lw_hip_srs_create", "lw_hip_srs_create_device", "lw_hip_srs_destroy", "lw_hip_msm_srs", "lw_hip_msm_srs_device",
     "lw_hip_msm_srs_fr", "lw_hip_msm_srs_fr_device", "lw_stark_fri_layer_device", "lw_groth16_h_coefficients_device",
     "lw_hip_ec_add_outer_device",
@@ -111,6 +111,8 @@ def lib():
     L.lw_stark_commit_columns.restype = i
     L.lw_stark_commit_columns_device.argtypes = [i, vp, u32, C.c_uint64, u32, i, vp, vp, vp]
     L.lw_stark_commit_columns_device.restype = i
+    L.lw_stark_commit_columns_layout_device.argtypes = [i, i, vp, u32, C.c_uint64, u32, i, vp, vp, vp]
+    L.lw_stark_commit_columns_layout_device.restype = i
     L.lw_stark_fri_layer.argtypes = [i, vp, sz, vp, vp, sz, vp, C.POINTER(sz), vp, vp, vp]
     L.lw_stark_fri_layer.restype = i
     L.lw_groth16_h_coefficients.argtypes = [vp, vp, vp, sz, sz, vp, C.POINTER(sz)]

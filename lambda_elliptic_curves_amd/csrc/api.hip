@@ -282,7 +282,7 @@ int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t
                       uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream,
                       uint32_t in_log2 = 0xffffffffu);
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
-                         void *d_nodes, hipStream_t stream);
+                         void *d_nodes, hipStream_t stream, uint32_t elem_bytes = 32);
 int fri_layer_device(Context &c, lw_field_t field, const void *d_coeffs, uint64_t n, const uint32_t *d_zeta, const void *offset_ref,
                      uint32_t log2_domain, void *d_poly, uint32_t log2_block, void *d_eval, void *d_eval_br, void *d_nodes,
                      hipStream_t stream);
@@ -922,6 +922,31 @@ static int msm_device_entry(lw_curve_t curve, const uint64_t *d_scalars, const v
     return rc;
 }
 // interpolate_and_commit_main's commitment step (provers/stark/src/prover.rs:229-244) on device-resident LDE columns
+// the element size the commitment hashes, or 0 when the (field, layout) pair has no AsBytes in the reference
+static uint32_t commit_elem_bytes(lw_field_t field, lw_layout_t layout) {
+    if (check_field_layout(field, layout)) return 0;
+    if (layout == LW_LAYOUT_EXT4_INTERLEAVED) { set_error("the quartic extension has no AsBytes in the reference (quartic_babybear.rs)"); return 0; }
+    return (uint32_t)lw_hip_field_elem_bytes(field, layout);
+}
+int lw_stark_commit_columns_layout_device(lw_field_t field, lw_layout_t layout, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems,
+                                          uint32_t log2n, int bit_reverse, void *d_nodes, uint8_t *out_root, void *hip_stream) {
+    const uint32_t eb = commit_elem_bytes(field, layout);
+    if (!eb) return LW_ERR_BAD_ARG;
+    if (!d_columns || !d_nodes || n_cols == 0) { set_error("null buffer or no columns"); return LW_ERR_BAD_ARG; }
+    if (log2n > 31) { set_error("2^%u leaves", log2n); return LW_ERR_ALLOC; }
+    if ((uint64_t)n_cols * eb >= (1ull << 31)) { set_error("%u columns per row", n_cols); return LW_ERR_BAD_ARG; }
+    Entry en(hip_stream);
+    if (en.rc) return en.rc;
+    Context &c = en.c;
+    if (col_stride_elems == 0) col_stride_elems = 1ull << log2n;
+    int rc = merkle_commit_device(c, d_columns, n_cols, col_stride_elems, log2n, bit_reverse, d_nodes, (hipStream_t)hip_stream, eb);
+    if (rc) return rc;
+    if (out_root) {
+        LW_HIP_CHECK(hipMemcpyAsync(out_root, d_nodes, 32, hipMemcpyDeviceToHost, (hipStream_t)hip_stream), LW_ERR_LAUNCH);
+        LW_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream), LW_ERR_LAUNCH);
+    }
+    return LW_OK;
+}
 int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems, uint32_t log2n,
                                    int bit_reverse, void *d_nodes, uint8_t *out_root, void *hip_stream) {
     if (field != LW_FIELD_STARK252 && field != LW_FIELD_BLS12_381_FR) { set_error("Merkle commitment supports the 256-bit fields"); return LW_ERR_BAD_ARG; }

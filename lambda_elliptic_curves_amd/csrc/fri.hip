@@ -15,7 +15,7 @@ namespace lw {
 int ntt_device_locked(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t dir, const void *d_in, void *d_out,
                       uint32_t log2n, uint32_t batch, size_t stride, const void *coset, hipStream_t stream, uint32_t in_log2);
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
-                         void *d_nodes, hipStream_t stream);
+                         void *d_nodes, hipStream_t stream, uint32_t elem_bytes = 32);
 int bitrev_device(size_t elem_bytes, const void *d_in, void *d_out, uint32_t log2n, hipStream_t stream);
 
 // out[i] = 2 * (c[2i] + zeta * c[2i+1]) for i < n_out; zeros up to `padded`

@@ -79,15 +79,37 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&st)[25]) {
     for (int i = 0; i < 25; i++) st[i] = ((uint64_t)a[i].hi << 32) | a[i].lo;
 }
 
-// one work-item per leaf; columns[c] starts at cols + c * col_stride elements (4 u64 limbs each, reference layout)
-__global__ __launch_bounds__(256) void merkle_leaves_kernel(const uint64_t *cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n,
+// one work-item per leaf; columns[c] starts at cols + c * col_stride elements.  EB = bytes per element as the reference keeps
+// it in memory; as_bytes of an element is its raw (Montgomery) value big-endian:
+//   32: MontgomeryBackendPrimeField<_, 4>, four u64 limbs most significant first (montgomery_backed_prime_fields.rs:367-373)
+//    8: MontgomeryBackendPrimeField<_, 1> (BabyBear on a u64 limb), the limb big-endian (same impl)
+//    4: U32MontgomeryBackendPrimeField (BabyBear u32), value().to_be_bytes() (u32_montgomery_backend_prime_field.rs:258-262)
+template <int EB>
+__global__ __launch_bounds__(256) void merkle_leaves_kernel(const void *cols_v, uint32_t n_cols, uint64_t col_stride, uint32_t log2n,
                                                             int bit_reverse, uint64_t *nodes) {
     const uint64_t n = 1ull << log2n;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t src = bit_reverse ? (log2n ? (uint64_t)(__brevll(i) >> (64 - log2n)) : 0) : i;
-    const uint32_t total = 4 * n_cols;             // 8-byte lanes of leaf data
-    const uint32_t nblocks = total / 17 + 1;       // rate = 17 lanes; the padding always adds at least one byte
+    const uint32_t total_bytes = (uint32_t)EB * n_cols;
+    const uint32_t total = total_bytes / 8;         // whole 8-byte lanes of leaf data
+    const uint32_t tail = total_bytes % 8;          // 4 for an odd number of u32 columns, else 0
+    const uint32_t nblocks = total_bytes / 136 + 1; // rate = 17 lanes = 136 bytes; the padding always adds at least one byte
+    // a Keccak lane is 8 stream bytes little-endian; lane s of the leaf's byte stream
+    auto lane = [&](uint32_t s) -> uint64_t {
+        if constexpr (EB == 32) {
+            const uint64_t *cols = (const uint64_t *)cols_v;
+            return __builtin_bswap64(cols[((uint64_t)(s >> 2) * col_stride + src) * 4 + (s & 3)]);
+        } else if constexpr (EB == 8) {
+            const uint64_t *cols = (const uint64_t *)cols_v;
+            return __builtin_bswap64(cols[(uint64_t)s * col_stride + src]);
+        } else {
+            const uint32_t *cols = (const uint32_t *)cols_v;
+            const uint32_t e0 = cols[(uint64_t)(2 * s) * col_stride + src];
+            const uint32_t e1 = 2 * s + 1 < n_cols ? cols[(uint64_t)(2 * s + 1) * col_stride + src] : 0u;
+            return (uint64_t)__builtin_bswap32(e0) | ((uint64_t)__builtin_bswap32(e1) << 32);
+        }
+    };
     uint64_t st[25];
 #pragma unroll
     for (int k = 0; k < 25; k++) st[k] = 0;
@@ -96,11 +118,10 @@ __global__ __launch_bounds__(256) void merkle_leaves_kernel(const uint64_t *cols
         for (int j = 0; j < 17; j++) {
             const uint32_t s = 17 * b + j;
             if (s < total) {
-                // as_bytes = big-endian limbs, most significant limb first; a Keccak lane is 8 stream bytes little-endian
-                const uint64_t limb = cols[((uint64_t)(s >> 2) * col_stride + src) * 4 + (s & 3)];
-                st[j] ^= __builtin_bswap64(limb);
+                st[j] ^= lane(s);
             } else if (s == total) {
-                st[j] ^= 0x01ull;                  // first padding byte
+                if (tail) st[j] ^= lane(s);              // the last u32 of an odd row (upper half zero)
+                st[j] ^= 0x01ull << (8 * tail);          // first padding byte
             }
         }
         if (b + 1 == nblocks) st[16] ^= 0x8000000000000000ull;   // last padding byte of the rate
@@ -155,11 +176,16 @@ __global__ __launch_bounds__(256) void merkle_top_kernel(uint64_t *nodes, uint64
 
 // d_nodes: (2 * 2^log2n - 1) * 32 bytes, root first
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
-                         void *d_nodes, hipStream_t stream) {
+                         void *d_nodes, hipStream_t stream, uint32_t elem_bytes) {
     const uint64_t n = 1ull << log2n;
     hipEvent_t pe = c.prof_begin(stream);
-    hipLaunchKernelGGL(merkle_leaves_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, (const uint64_t *)d_cols, n_cols,
-                       col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+    const dim3 grid((uint32_t)((n + 255) / 256));
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((merkle_leaves_kernel<4>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+    else if (elem_bytes == 8)
+        hipLaunchKernelGGL((merkle_leaves_kernel<8>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+    else
+        hipLaunchKernelGGL((merkle_leaves_kernel<32>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
     c.prof_end("merkle_leaves_kernel", pe, stream);
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     // crypto/src/merkle_tree/utils.rs:44-72

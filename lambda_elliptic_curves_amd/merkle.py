@@ -37,6 +37,19 @@ def commit_columns_device(field, t_columns, n_cols, log2n, t_nodes, bit_reverse=
     return root.tobytes()
 
 
+def commit_columns_layout_device(field, t_columns, n_cols, log2n, t_nodes, bit_reverse=True, stream=None):
+    """commit_columns_device for any layout with an AsBytes in the reference (BabyBear u32 / u64-limb columns: the STARK LDE
+    of BASELINE config 4)."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    root = np.zeros(32, np.uint8)
+    check(L.lib().lw_stark_commit_columns_layout_device(field.field, field.layout, C.c_void_p(t_columns.data_ptr()), n_cols, 0, log2n,
+                                                        1 if bit_reverse else 0, C.c_void_p(t_nodes.data_ptr()),
+                                                        root.ctypes.data_as(C.c_void_p), C.c_void_p(stream)))
+    return root.tobytes()
+
+
 def fri_layer(field, coeffs, zeta, coset_offset, domain_size, return_nodes=False):
     """One layer of commit_phase (provers/stark/src/fri/mod.rs:44-58): returns (p' = 2*fold(p, zeta) coefficients,
     bit-reversed evaluation of p' on coset_offset * <w_domain>, Merkle root [, nodes])."""

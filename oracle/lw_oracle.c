@@ -771,16 +771,25 @@ int orc_merkle_commit_columns(const u64 *columns, uint32_t n_cols, uint32_t log2
 
 /* Leaves and every tree level are independent hashes; the checker at the sizes the GPU path is timed on (2^22-2^24
    leaves) splits exactly the loops of orc_merkle_commit_columns over `threads` workers.  Same nodes, same order. */
-typedef struct { const u64 *columns; uint32_t n_cols; size_t n; int bit_reverse; uint8_t *nodes; size_t level_begin, new_begin, lo, hi; int leaves; } mk_job;
+typedef struct { const u64 *columns; uint32_t n_cols; size_t n; int bit_reverse; uint8_t *nodes; size_t level_begin, new_begin, lo, hi; int leaves; uint32_t eb; } mk_job;
+/* as_bytes of one element: eb = 32: four u64 limbs big-endian (montgomery_backed_prime_fields.rs:367-373); 8: the one limb of
+   the u64-limb BabyBear, same impl; 4: U32MontgomeryBackendPrimeField's value().to_be_bytes()
+   (u32_montgomery_backend_prime_field.rs:258-262) */
+static void elem_as_bytes_eb(const void *columns, uint32_t eb, size_t index, uint8_t *out) {
+    if (eb == 32) elem_as_bytes_be((const u64 *)columns + index * 4, 4, out);
+    else if (eb == 8) elem_as_bytes_be((const u64 *)columns + index, 1, out);
+    else { u32 v = ((const u32 *)columns)[index]; out[0] = (uint8_t)(v >> 24); out[1] = (uint8_t)(v >> 16); out[2] = (uint8_t)(v >> 8); out[3] = (uint8_t)v; }
+}
 static void *mk_worker(void *arg) {
     mk_job *j = (mk_job *)arg;
     if (j->leaves) {
-        uint8_t *row = (uint8_t *)malloc((size_t)j->n_cols * 32 + 1);
+        const uint32_t eb = j->eb ? j->eb : 32;
+        uint8_t *row = (uint8_t *)malloc((size_t)j->n_cols * eb + 1);
         uint8_t *leaves = j->nodes + (j->n - 1) * 32;
         for (size_t i = j->lo; i < j->hi; i++) {
             size_t src = j->bit_reverse ? ntt4_reverse_index(i, j->n) : i;
-            for (uint32_t c = 0; c < j->n_cols; c++) elem_as_bytes_be(j->columns + ((size_t)c * j->n + src) * 4, 4, row + (size_t)c * 32);
-            orc_keccak256(row, (size_t)j->n_cols * 32, leaves + i * 32);
+            for (uint32_t c = 0; c < j->n_cols; c++) elem_as_bytes_eb(j->columns, eb, (size_t)c * j->n + src, row + (size_t)c * eb);
+            orc_keccak256(row, (size_t)j->n_cols * eb, leaves + i * 32);
         }
         free(row);
     } else {
@@ -812,9 +821,17 @@ static void mk_run(mk_job *proto, size_t count, int threads) {
     }
     for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
 }
+/* the same tree over columns of elem_bytes-byte elements (32, 8 or 4), see elem_as_bytes_eb */
+int orc_merkle_commit_columns_bytes(const void *columns, uint32_t elem_bytes, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out,
+                                    int threads);
 int orc_merkle_commit_columns_mt(const u64 *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out, int threads) {
+    return orc_merkle_commit_columns_bytes(columns, 32, n_cols, log2n, bit_reverse, nodes_out, threads);
+}
+int orc_merkle_commit_columns_bytes(const void *columns, uint32_t elem_bytes, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out,
+                                    int threads) {
+    if (elem_bytes != 32 && elem_bytes != 8 && elem_bytes != 4) return ORC_ERR_BAD_ARG;
     const size_t n = (size_t)1 << log2n;
-    mk_job j = { columns, n_cols, n, bit_reverse, nodes_out, 0, 0, 0, 0, 1 };
+    mk_job j = { (const u64 *)columns, n_cols, n, bit_reverse, nodes_out, 0, 0, 0, 0, 1, elem_bytes };
     mk_run(&j, n, threads);
     size_t level_begin = n - 1, level_end = 2 * level_begin;
     while (level_begin != level_end) {

@@ -67,6 +67,8 @@ int orc_gen_points(int curve, const void *gen, const uint64_t *s0, const uint64_
 
 int orc_keccak256_bytes(const uint8_t *data, size_t len, uint8_t *out32);
 int orc_merkle_commit_columns(const uint64_t *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out);
+int orc_merkle_commit_columns_bytes(const void *columns, uint32_t elem_bytes, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out,
+                                    int threads);
 int orc_merkle_commit_columns_mt(const uint64_t *columns, uint32_t n_cols, uint32_t log2n, int bit_reverse, uint8_t *nodes_out, int threads);
 /* 2 * fold_polynomial(p, zeta) (provers/stark/src/fri/mod.rs:49, fri/fri_functions.rs:7-30) */
 int orc_fri_fold_twice(int field, const uint64_t *coeffs, size_t n, const uint64_t *zeta, uint64_t *out, size_t *out_len);

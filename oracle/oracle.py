@@ -400,6 +400,19 @@ def merkle_commit_columns(columns, bit_reverse=True, threads=1):
     return nodes
 
 
+def merkle_commit_columns_babybear(columns, bit_reverse=True, threads=1):
+    """The same commitment over BabyBear columns: (n_cols, N) uint32 (U32MontgomeryBackendPrimeField: value().to_be_bytes(),
+    u32_montgomery_backend_prime_field.rs:258-262) or uint64 (the u64-limb backend: its one limb big-endian)."""
+    cols = np.ascontiguousarray(columns)
+    assert cols.dtype in (np.uint32, np.uint64) and cols.ndim == 2
+    n_cols, n = cols.shape
+    log2n = n.bit_length() - 1
+    assert 1 << log2n == n
+    nodes = np.zeros((2 * n - 1, 32), np.uint8)
+    _chk(lib().orc_merkle_commit_columns_bytes(_p(cols), cols.dtype.itemsize, n_cols, log2n, 1 if bit_reverse else 0, _p(nodes), threads))
+    return nodes
+
+
 def fri_fold_twice(field, coeffs, zeta, strip=True):
     """2 * fold_polynomial(p, zeta) (provers/stark/src/fri/mod.rs:49, fri/fri_functions.rs:7-30) on 4-limb elements."""
     a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)

@@ -152,6 +152,9 @@ extern "C" {
     pub fn lw_stark_commit_columns_device(field: Field, d_columns: *const c_void, n_cols: u32, col_stride_elems: u64, log2n: u32,
                                           bit_reverse: c_int, d_nodes: *mut c_void, out_root_or_null: *mut u8,
                                           hip_stream: *mut c_void) -> c_int;
+    pub fn lw_stark_commit_columns_layout_device(field: Field, layout: Layout, d_columns: *const c_void, n_cols: u32, col_stride_elems: u64,
+                                                 log2n: u32, bit_reverse: c_int, d_nodes: *mut c_void, out_root_or_null: *mut u8,
+                                                 hip_stream: *mut c_void) -> c_int;
     pub fn lw_stark_fri_layer(field: Field, coeffs: *const c_void, n_coeffs: usize, zeta: *const c_void, coset_offset: *const c_void,
                               domain_size: usize, out_poly: *mut c_void, out_poly_len: *mut usize, out_evaluation: *mut c_void,
                               out_root: *mut u8, out_nodes_or_null: *mut u8) -> c_int;

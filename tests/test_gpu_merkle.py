@@ -60,3 +60,33 @@ def test_fri_layer_matches_reference_composition(n_coeffs, domain):
     assert np.array_equal(poly, exp_poly)
     assert np.array_equal(ev, exp_ev)
     assert np.array_equal(nodes, exp_nodes) and root == exp_nodes[0].tobytes()
+
+
+@pytest.mark.parametrize("name", ["babybear_u32", "babybear_u64"])
+@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 3), (3, 5), (4, 10), (33, 6), (35, 4), (17, 9)])
+def test_babybear_commit_matches_oracle(name, n_cols, log_n):
+    """The commitment over BabyBear columns (BASELINE config 4's field): leaves hash the raw words big-endian, 4 or 8 bytes per
+    element; odd u32 column counts leave half a Keccak lane before the padding, 35 columns span two blocks."""
+    import torch
+    from lambda_elliptic_curves_amd import merkle
+    fld, _ = util.field_pairs()[name]
+    n = 1 << log_n
+    cols = np.stack([util.rand_elems(name, n, 1900 + 7 * c + log_n) for c in range(n_cols)])
+    t_cols = torch.from_numpy(cols.view(np.int32 if cols.dtype == np.uint32 else np.int64)).cuda()
+    t_nodes = torch.empty(((2 * n - 1) * 4,), dtype=torch.int64, device="cuda")
+    for br in (True, False):
+        root = merkle.commit_columns_layout_device(fld, t_cols, n_cols, log_n, t_nodes, bit_reverse=br)
+        exp = O.merkle_commit_columns_babybear(cols, br)
+        assert np.array_equal(t_nodes.cpu().numpy().view(np.uint8).reshape(2 * n - 1, 32), exp)
+        assert root == exp[0].tobytes()
+
+
+def test_commit_layout_entry_rejects_the_extension_layout_and_serves_256_bit_fields():
+    import torch
+    from lambda_elliptic_curves_amd import errors, fft, merkle
+    cols = np.stack([util.rand_elems("stark252", 64, 5 + c) for c in range(2)])
+    t_cols = torch.from_numpy(cols.view(np.int64)).cuda()
+    t_nodes = torch.empty((127 * 4,), dtype=torch.int64, device="cuda")
+    assert merkle.commit_columns_layout_device(fft.Stark252PrimeField, t_cols, 2, 6, t_nodes) == O.merkle_commit_columns(cols, True)[0].tobytes()
+    with pytest.raises(errors.HipError):
+        merkle.commit_columns_layout_device(fft.Degree4BabyBearExtensionField, t_cols, 1, 6, t_nodes)

@@ -38,6 +38,35 @@ def test_merkle_commit_at_bench_sizes(n_cols, log_n):
     assert hashlib.sha256(got.tobytes()).digest() == hashlib.sha256(exp.tobytes()).digest()
 
 
+def test_config4_lde_then_commit_stays_on_device():
+    """BASELINE config 4 end to end on one GPU: the STARK LDE of four BabyBear columns (2^22 coefficients -> 2^24 evaluations on
+    the coset 3<w>, lw_hip_ntt_lde_device) and the Merkle commitment of the result (prover.rs:208-244), nothing leaving HBM
+    but the root; against the oracle's padded transforms and its tree."""
+    import torch
+    from lambda_elliptic_curves_amd import fft, merkle
+    fld, oid = util.field_pairs()["babybear_u32"]
+    B, log_m, blow = 4, 22, 2
+    n, N = 1 << log_m, 1 << (log_m + blow)
+    coeffs = [util.rand_elems("babybear_u32", n, 6100 + c) for c in range(B)]
+    off = util.offset_elem("babybear_u32", 3)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(4) as ex:
+        futs = [ex.submit(O.evaluate_fft, oid, c, 1 << blow, n, off) for c in coeffs]
+        t_c = torch.from_numpy(np.concatenate(coeffs).view(np.int32)).cuda()
+        t_lde = torch.empty(B * N, dtype=torch.int32, device="cuda")
+        t_nodes = torch.empty(((2 * N - 1) * 4,), dtype=torch.int64, device="cuda")
+        fft.lde_device(fld, t_c, log_m, t_lde, log_m + blow, batch=B, offset=off)
+        root = merkle.commit_columns_layout_device(fld, t_lde, B, log_m + blow, t_nodes)
+        exp_cols = np.stack([np.asarray(f.result()).reshape(-1) for f in futs])
+    assert np.array_equal(t_lde.cpu().numpy().view(np.uint32).reshape(B, N), exp_cols)
+    exp = O.merkle_commit_columns_babybear(exp_cols, True, threads=util.host_threads())
+    assert root == exp[0].tobytes()
+    got = t_nodes.cpu().numpy().view(np.uint8).reshape(2 * N - 1, 32)
+    for i in _nodes_sample(2 * N - 1):
+        assert np.array_equal(got[i], exp[i]), f"node {i}"
+    assert hashlib.sha256(got.tobytes()).digest() == hashlib.sha256(exp.tobytes()).digest()
+
+
 def test_groth16_h_stays_on_device_and_feeds_the_msm():
     """Prover::prove (provers/groth16/src/prover.rs:68-72,97-101): h = calculate_h_coefficients(w), then
     msm(h.representative(), z_powers_of_tau_g1[..h.len()]).  2^20 gates; h never leaves HBM between the two."""

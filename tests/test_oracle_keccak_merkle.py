@@ -99,3 +99,21 @@ def test_groth16_h_restatement_matches_composition():
     k = 5
     l, r, o = (util.rand_elems("fr381", k, s) for s in (1, 2, 3))
     assert np.array_equal(O.groth16_h_coefficients(l, r, o, 16), util.groth16_h_by_composition(l, r, o, 16))
+
+
+def test_babybear_leaves_hash_the_raw_words_big_endian():
+    # U32MontgomeryBackendPrimeField::as_bytes = value().to_be_bytes() (u32_montgomery_backend_prime_field.rs:258-262); the
+    # u64-limb BabyBear hashes its one limb big-endian (montgomery_backed_prime_fields.rs:367-373): leaves by definition
+    rng = np.random.default_rng(1)
+    n = 8
+    rev = lambda i: int("{:03b}".format(i)[::-1], 2)
+    for dt in (np.uint32, np.uint64):
+        for n_cols in (1, 3, 4, 35):          # 35 u32 columns = 140 bytes: two Keccak blocks, odd word count
+            cols = rng.integers(0, util.P_BABYBEAR, size=(n_cols, n), dtype=dt)
+            nodes = O.merkle_commit_columns_babybear(cols, True, threads=1)
+            for i in range(n):
+                row = b"".join(int(cols[c, rev(i)]).to_bytes(cols.dtype.itemsize, "big") for c in range(n_cols))
+                assert nodes[n - 1 + i].tobytes() == O.keccak256(row), (dt, n_cols, i)
+            for k in range(n - 1):
+                assert nodes[k].tobytes() == O.keccak256(nodes[2 * k + 1].tobytes() + nodes[2 * k + 2].tobytes())
+            assert np.array_equal(nodes, O.merkle_commit_columns_babybear(cols, True, threads=4))
