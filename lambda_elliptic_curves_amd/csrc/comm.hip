@@ -494,7 +494,8 @@ int lw_hip_comm_shutdown(void) {
 }
 
 int lw_hip_comm_info(int *rank, int *nranks) {
-    std::lock_guard<std::mutex> g(lane(0).mu);   // the communicator lives with lane 0
+    std::lock_guard<std::mutex> g(lane(0).mu);   // the communicator lives with lane 0 (lock order: lane, then the shared hold)
+    std::shared_lock<std::shared_mutex> sl(shared_state().rw);   // ... and shutdown releases it holding rw exclusively
     if (!g_comm.comm) { set_error("no communicator: call lw_hip_comm_init first"); return LW_ERR_COMM; }
     if (rank) *rank = g_comm.rank;
     if (nranks) *nranks = g_comm.nranks;

@@ -99,6 +99,31 @@ def test_256_bit_ntt_and_intt_2_24_match_oracle(L):
             assert np.array_equal(got[key], f.result()), key
 
 
+def test_stark252_ntt_and_intt_2_26_match_oracle():
+    """The upper end of BASELINE config 2 (2 GiB per buffer, the four-pass plan 6 + 6 + 6 + 8): forward and inverse byte for byte
+    against the oracle's single-threaded evaluate_fft / interpolate_fft (about 40 s each, run side by side on two host
+    threads while the GPU results are produced)."""
+    import torch
+    from lambda_elliptic_curves_amd import fft
+    fld, oid = util.field_pairs()["stark252"]
+    L = 26
+    a = util.rand_elems("stark252", 1 << L, 0x5EED0000 + L)
+    with ThreadPoolExecutor(2) as ex:
+        f_fwd = ex.submit(O.evaluate_fft, oid, a)
+        f_inv = ex.submit(O.interpolate_fft, oid, a)
+        t_in = torch.from_numpy(a.view(np.int64)).cuda()
+        t_out = torch.empty_like(t_in)
+        fft.ntt_device(fld, t_in, t_out, L)
+        torch.cuda.synchronize()
+        fwd = t_out.cpu().numpy().view(np.uint64)
+        fft.ntt_device(fld, t_in, t_out, L, inverse=True)
+        torch.cuda.synchronize()
+        inv = t_out.cpu().numpy().view(np.uint64)
+        del t_in, t_out
+        assert np.array_equal(fwd, f_fwd.result()), "forward 2^26"
+        assert np.array_equal(inv, f_inv.result()), "inverse 2^26"
+
+
 @pytest.mark.parametrize("name", ["babybear_u32", "babybear_u64"])
 def test_babybear_4_columns_2_24_match_oracle(name):
     # BASELINE config 4's workload on one GPU: 4 columns x 2^24, one batched call; every column against the oracle
