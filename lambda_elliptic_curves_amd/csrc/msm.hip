@@ -165,28 +165,38 @@ template <> struct ItemMem<uint64_t> {
     __device__ __forceinline__ void store(uint32_t i, uint64_t it) const { lo[i] = (uint32_t)it; hi[i] = (uint16_t)(it >> 32); }
 };
 
-// exclusive scan of a[0 .. NMAX) in LDS by the whole workgroup (tmp: SORT_THREADS words); returns the total
+// exclusive scan of a[0 .. NMAX) in LDS by the whole workgroup (tmp: SORT_THREADS words); returns the total.
+// Round 3: the scan across the 512 work-items is a wave-level shuffle scan (6 steps, no barrier) plus the 8 wave totals —
+// three barriers per call where the Hillis-Steele loop over LDS took eighteen; every 8192-item chunk of the coarse and
+// fine scatters calls it once, and a workgroup's time was mostly those barriers.
 template <uint32_t NMAX>
 __device__ __forceinline__ uint32_t block_scan_exclusive(uint32_t *a, uint32_t *tmp) {
     constexpr uint32_t PER = NMAX / SORT_THREADS;
     static_assert(PER * SORT_THREADS == NMAX, "scan size");
-    const uint32_t tid = threadIdx.x;
+    static_assert(SORT_THREADS / 64 <= 64, "one wave scans the wave totals");
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t v[PER], sum = 0;
 #pragma unroll
     for (uint32_t i = 0; i < PER; i++) {
         v[i] = a[tid * PER + i];
         sum += v[i];
     }
-    tmp[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < SORT_THREADS; d <<= 1) {
-        const uint32_t x = tid >= d ? tmp[tid - d] : 0;
-        __syncthreads();
-        tmp[tid] += x;
-        __syncthreads();
+    uint32_t inc = sum;   // inclusive scan inside the wave
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t x = __shfl_up(inc, d);
+        if (lane >= d) inc += x;
     }
-    const uint32_t total = tmp[SORT_THREADS - 1];
-    uint32_t run = tmp[tid] - sum;
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SORT_THREADS / 64; w++) {
+        const uint32_t t = tmp[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    uint32_t run = wbase + inc - sum;
 #pragma unroll
     for (uint32_t i = 0; i < PER; i++) {
         a[tid * PER + i] = run;
@@ -805,6 +815,9 @@ int ensure_aux_stream(Context &c) {
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // (hipDeviceGetStreamPriorityRange: numerically lower = higher priority)
+    // (Measured, profiles/r03_ab_msm_normcus.txt: a side stream restricted to 64-192 CUs, so that the normalisation takes a smaller
+    // share of HBM from the sort on the critical path — the sort kernels then run at their standalone times but the
+    // normalisation takes 3.5-7.9 ms and the MSM 47.2-52.4 ms against 45.4.)
     if (hipStreamCreateWithPriority(&c.aux_stream, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&c.aux_hi, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c.aux_fork, hipEventDisableTiming) != hipSuccess ||
