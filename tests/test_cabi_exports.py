@@ -56,6 +56,15 @@ def test_product_never_touches_the_oracle():
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
 
 
+def test_tools_do_not_use_the_checker():
+    # oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs may import it
+    # (tests/util.py does, so the tools take their inputs from tools/inputs.py instead)
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if f.endswith(".py"):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", text, re.M), f"tools/{f} imports the checker"
+
+
 def test_rust_shim_declares_every_symbol_and_status():
     # rust-shim/src/ffi.rs cannot be compiled here (no Rust toolchain); at least keep it in step with the header
     ffi = open(os.path.join(ROOT, "rust-shim", "src", "ffi.rs")).read()

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from lambda_elliptic_curves_amd import _lib, fft
-from tests import util
+from tools import inputs as util
 fp = util.field_pairs()
 for tag, name, L, batch in (("u32 4x2^24", "babybear_u32", 24, 4), ("u64 4x2^24", "babybear_u64", 24, 4), ("ext4 2^24", "babybear_ext4", 24, 1),
                             ("u32 4x2^20", "babybear_u32", 20, 4), ("u32 1x2^22", "babybear_u32", 22, 1)):

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from lambda_elliptic_curves_amd import _lib, merkle, fft
-from tests import util
+from tools import inputs as util
 fld = util.field_pairs()["stark252"][0]
 for ncols, L in ((4, 22), (1, 24), (16, 20)):
     n = 1 << L

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lambda_elliptic_curves_amd import fft, _lib
-from tests import util
+from tools import inputs as util
 fld = fft.Babybear31PrimeFieldU32
 L, batch = 24, 4
 a = util.rand_elems("babybear_u32", (1 << L) * batch, 1)

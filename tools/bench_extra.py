@@ -14,8 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import torch
     from lambda_elliptic_curves_amd import _lib, fft, msm
-    from oracle import oracle as O
-    from tests import util
+    from tools import inputs as util
     from tools.synth import distinct_points
     out = {}
 
@@ -106,24 +105,7 @@ def main():
     dt = (time.perf_counter() - t0) / 2
     out["bls12_381_g1_2^22_host_buffers"] = {"ms": dt * 1e3, "points_per_s": n / dt}
     print("bls12_381_g1_2^22_host_buffers", out["bls12_381_g1_2^22_host_buffers"], flush=True)
-    # CPU context (SURVEY 8d ii/iv): the oracle's restatement on all host cores the box gives this process —
-    # column-parallel NTT batch (what provers/stark/src/trace.rs:186-190 does with rayon) and window-parallel MSM
-    from concurrent.futures import ThreadPoolExecutor
-    threads = min(16, os.cpu_count() or 1)
-    cols = [util.rand_elems("stark252", 1 << 20, 100 + k) for k in range(threads)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(lambda a: O.evaluate_fft(O.F_STARK252, a), cols))
-    dt = time.perf_counter() - t0
-    out["cpu_stark252_%dcols_2^20_%dthreads" % (threads, threads)] = {"s": dt, "elements_per_s": threads * (1 << 20) / dt, "threads": threads}
-    print("cpu column-parallel NTT", out["cpu_stark252_%dcols_2^20_%dthreads" % (threads, threads)], flush=True)
-    crv, oid = util.curve_pairs()["bls12_381_g1"]
-    sc_c, pts_c = util.msm_case(oid, 1 << 20, 0x5EED)
-    t0 = time.perf_counter()
-    O.parallel_msm_with(oid, sc_c, pts_c, O.optimum_window_size(1 << 20), threads)
-    dt = time.perf_counter() - t0
-    out["cpu_bls12_381_g1_2^20_%dthreads" % threads] = {"s": dt, "points_per_s": (1 << 20) / dt, "threads": threads}
-    print("cpu window-parallel MSM", out["cpu_bls12_381_g1_2^20_%dthreads" % threads], flush=True)
+    # (the CPU context rows — column-parallel NTT and window-parallel MSM on all host cores — are bench.py's cpu_all_cores)
     json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/bench_extra.json", "w"), indent=1)
 
 
