@@ -86,6 +86,19 @@ struct FpOps {
         for (int i = 0; i < F::N; i++) r.v[i] = c ? a.v[i] : b.v[i];
         return r;
     }
+    // value held by another lane, one DPP move per limb; device code only.  CTRL: 0x00-0xFF quad_perm (lane i of a quad
+    // reads lane (CTRL >> 2i) & 3), 0x110 + n row_shr:n (lane i reads lane i - n of its row of 16)
+    template <int CTRL>
+    LW_HD static T dpp(const T &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        T r;
+#pragma unroll
+        for (int i = 0; i < F::N; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], CTRL, 0xF, 0xF, true);
+        return r;
+#else
+        return a;
+#endif
+    }
     LW_HD static T zero() { return T::zero(); }
     LW_HD static T one() { return T::one(); }
     LW_HD static bool is_zero(const T &a) { return a.is_zero(); }
@@ -152,6 +165,8 @@ struct Fp2Ops {
     LW_HD static T dbl(const T &a) { return add(a, a); }
     LW_HD static T lane_swap(const T &a) { return T{FpOps<F>::lane_swap(a.c0), FpOps<F>::lane_swap(a.c1)}; }
     LW_HD static T select(bool c, const T &a, const T &b) { return T{FpOps<F>::select(c, a.c0, b.c0), FpOps<F>::select(c, a.c1, b.c1)}; }
+    template <int CTRL>
+    LW_HD static T dpp(const T &a) { return T{FpOps<F>::template dpp<CTRL>(a.c0), FpOps<F>::template dpp<CTRL>(a.c1)}; }
     LW_HD static T zero() { return T{Fe<F>::zero(), Fe<F>::zero()}; }
     LW_HD static T one() { return T{Fe<F>::one(), Fe<F>::zero()}; }
     LW_HD static bool is_zero(const T &a) { return a.c0.is_zero() && a.c1.is_zero(); }
@@ -369,6 +384,36 @@ LW_HD Point<C> pt_dbl(const Point<C> &p) {
     x3 = B::mul(t0, t1);
     x3 = B::dbl(x3);
     return Point<C>{x3, y3, z3};
+}
+
+// The same complete addition spread over the lanes s = 0, 1, 2 of a quad (lane 3 mirrors lane 0): lane s holds coordinate
+// s (X, Y, Z) of both operands and returns coordinate s of the sum.  A chain of dependent additions run by ONE lane costs
+// 6 products + 3 dots = 21 N^2 MACs per link; here a link is 2 products + 1 dot = 7 N^2 per lane:
+//   lane s:  P_s = a_s b_s,  C_s = (a_s + a_s+1)(b_s + b_s+1) - P_s - P_s+1      (indices mod 3)
+//   i.e.     t0, t1, t2 = P_0, P_1, P_2   and   t3, t4, y3 = C_0, C_1, C_2   of the formula above, broadcast by quad_perm,
+//   lane 0:  X3 = t3 t1' - t4 (b3 y3),  lane 1:  Y3 = t1' z3 + (b3 y3)(3 t0),  lane 2:  Z3 = z3 t4 + (3 t0) t3
+// with t1' = t1 - b3 t2, z3 = t1 + b3 t2 computed by every lane.  For the latency-bound levels of the bucket reduce
+// (msm_core.cuh), where lanes are free and the chain is everything.  p + p is a valid input (complete formula), so the
+// doublings of the reduce use it too.
+template <class C>
+LW_HD typename C::B::T pt_add_quad(const typename C::B::T &a, const typename C::B::T &b, uint32_t s) {
+    using B = typename C::B;
+    using T = typename B::T;
+    constexpr int ROT1 = 0x49;   // quad_perm [1, 2, 0, 1]: lane s reads lane (s + 1) mod 3
+    const T a1 = B::template dpp<ROT1>(a), b1 = B::template dpp<ROT1>(b);
+    const T P = B::mul(a, b);
+    T Cs = B::mul(B::add(a, a1), B::add(b, b1));
+    Cs = B::sub(Cs, B::add(P, B::template dpp<ROT1>(P)));
+    const T t0 = B::template dpp<0x00>(P), t1 = B::template dpp<0x55>(P), t2 = C::mul_b3(B::template dpp<0xAA>(P));
+    const T t3 = B::template dpp<0x00>(Cs), t4 = B::template dpp<0x55>(Cs), y3 = C::mul_b3(B::template dpp<0xAA>(Cs));
+    const T z3 = B::add(t1, t2), t1m = B::sub(t1, t2);
+    const T t0x3 = B::add(B::add(t0, t0), t0);
+    const bool l0 = s == 0, l1 = s == 1;
+    const T oa = B::select(l0, t3, B::select(l1, t1m, z3));
+    const T ob = B::select(l0, t1m, B::select(l1, z3, t4));
+    const T oc = B::select(l0, B::neg(t4), B::select(l1, y3, t0x3));
+    const T od = B::select(l0, y3, B::select(l1, t0x3, t3));
+    return B::dot2(oa, ob, oc, od);
 }
 
 template <class C>

@@ -11,6 +11,7 @@ namespace lw {
 
 uint32_t msm_ch(uint64_t items);       // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
 int msm_piece_order_enabled();         // LW_HIP_MSM_ORDER=0: work-items take their pieces in key order (A/B)
+uint64_t msm_quad_max_lanes();          // levels of the bucket reduce with at most this many lanes (8 per group) spread each addition over a quad; 0 = never
 uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
@@ -240,9 +241,12 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_kernel(const void *
     const uint32_t w = pair / ngroups, j = pair - w * ngroups;
     const size_t base = (size_t)w * n;
     const uint32_t d0 = j * g, d1 = min(n, d0 + g);
-    Point<C> acc = pt_identity<C>();
+    // the first step would add the top bucket to the identity (and the identity to itself): start from it instead — a chain
+    // of g - 1 additions, 13 real ones per group of 8 where the plain loop computes 16
+    const Point<C> top = pt_ld<C>(in, base + d1 - 1), id = pt_identity<C>();
+    Point<C> acc = Point<C>{B::select(is_q, id.x, top.x), B::select(is_q, id.y, top.y), B::select(is_q, id.z, top.z)};
 #pragma nounroll
-    for (uint32_t d = d1; d-- > d0;) {
+    for (uint32_t d = d1 - 1; d-- > d0;) {
         const Point<C> x = pt_ld<C>(in, base + d);
         Point<C> operand;
         operand.x = B::select(is_q, B::lane_swap(acc.x), x.x);
@@ -263,6 +267,56 @@ __global__ void msm_combine_kernel(const void *S2, const void *A2, uint32_t k, u
     for (uint32_t i = 0; i < k; i++) x = pt_dbl<C>(x);
     pt_st<C>(S, w, pt_add<C>(pt_ld<C>(A2, nwin + w), x));
     pt_st<C>(A, w, pt_ld<C>(A2, w));
+}
+
+// The same two kernels for the levels that are nothing but a chain of dependent additions (a few thousand groups and
+// less): eight lanes per group — a quad for `running`, a quad for `q` — with every addition spread over the three lanes
+// of its quad (pt_add_quad, ec.cuh: 7 N^2 MACs per lane and link instead of 21).  Lane s of a quad loads, keeps and stores
+// coordinate s only; the q quad reads the running quad's coordinates by DPP (row_shr:4).  Same group elements as
+// msm_group_sum_kernel / msm_combine_kernel (another projective representative; the MSM result is normalised at the end).
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_group_sum_quad_kernel(const void *in, uint32_t n, uint32_t g, uint32_t ngroups,
+                                                                          uint32_t nwin, void *out) {
+    using B = typename C::B;
+    using T = typename B::T;
+    constexpr size_t PBY = 3 * B::BYTES;
+    static_assert(MSM_THREADS % 16 == 0, "groups of eight lanes must not straddle a DPP row");
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t grp = t >> 3;
+    if (grp >= ngroups * nwin) return;           // groups are never split: their eight lanes leave together
+    const bool is_q = (t >> 2) & 1;
+    const uint32_t s = (t & 3) == 3 ? 0u : (t & 3);
+    const uint32_t w = grp / ngroups, j = grp - w * ngroups;
+    const char *src = (const char *)in + (size_t)w * n * PBY + s * B::BYTES;
+    const uint32_t d0 = j * g, d1 = min(n, d0 + g);
+    // running starts from the top bucket, q from the identity (0 : 1 : 0): g - 1 links, as in msm_group_sum_kernel
+    T acc = B::select(is_q, s == 1 ? B::one() : B::zero(), B::load(src + (size_t)(d1 - 1) * PBY));
+#pragma nounroll
+    for (uint32_t d = d1 - 1; d-- > d0;) {
+        const T x = B::load(src + (size_t)d * PBY);
+        const T operand = B::select(is_q, B::template dpp<0x114>(acc), x);
+        acc = pt_add_quad<C>(acc, operand, s);
+    }
+    if ((t & 3) != 3) B::store((char *)out + ((size_t)(is_q ? nwin + w : w) * ngroups + j) * PBY + s * B::BYTES, acc);
+}
+template <class C>
+__global__ __launch_bounds__(64) void msm_combine_quad_kernel(const void *S2, const void *A2, uint32_t k, uint32_t nwin, void *S, void *A) {
+    using B = typename C::B;
+    using T = typename B::T;
+    constexpr size_t PBY = 3 * B::BYTES;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w = t >> 2;
+    if (w >= nwin) return;
+    const uint32_t s = (t & 3) == 3 ? 0u : (t & 3);
+    const size_t co = s * B::BYTES;
+    T x = B::load((const char *)S2 + (size_t)w * PBY + co);
+#pragma nounroll
+    for (uint32_t i = 0; i < k; i++) x = pt_add_quad<C>(x, x, s);
+    x = pt_add_quad<C>(B::load((const char *)A2 + (size_t)(nwin + w) * PBY + co), x, s);
+    if ((t & 3) != 3) {
+        B::store((char *)S + (size_t)w * PBY + co, x);
+        B::store((char *)A + (size_t)w * PBY + co, B::load((const char *)A2 + (size_t)w * PBY + co));
+    }
 }
 
 // ---------------------------------------------------------------- sharded MSM (comm.hip): bucket-slice exchange
@@ -385,6 +439,21 @@ struct MsmRunner {
         return LW_OK;
     }
 
+    // One level of the bucket reduce.  Wide levels (more groups than the chip has lanes for) are bound by the additions'
+    // throughput: two lanes per group.  The others are bound by the chain of g dependent additions: eight lanes per group,
+    // each addition spread over a quad (msm_group_sum_quad_kernel).
+    void launch_group_sum(const char *in, uint32_t n, uint32_t g, uint32_t ng, uint32_t nwin, char *out, hipStream_t stream) {
+        const uint64_t groups = (uint64_t)ng * nwin;
+        hipEvent_t pe = c.prof_begin(stream);
+        if (8 * groups <= msm_quad_max_lanes())
+            hipLaunchKernelGGL((msm_group_sum_quad_kernel<C>), dim3((uint32_t)((8 * groups + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                               stream, (const void *)in, n, g, ng, nwin, (void *)out);
+        else
+            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((uint32_t)((2 * groups + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
+                               stream, (const void *)in, n, g, ng, nwin, (void *)out);
+        c.prof_end("msm_group_sum_kernel", pe, stream);
+    }
+
     // in: nwin arrays of n points.  Returns device arrays S[nwin] (sum d*in[d]) and A[nwin] (sum in[d]).
     static constexpr size_t PB = 3 * C::B::BYTES;
     int reduce(const char *in, uint32_t n, uint32_t nwin, Carver &cv, char **S_out, char **A_out, hipStream_t stream) {
@@ -393,12 +462,7 @@ struct MsmRunner {
         if (n <= g) {   // one work-item per array: S = Q (d0 = 0), A = running sum
             char *out = (char *)cv.take(PB * 2 * (size_t)nwin);
             LW_MSM_WS_CHECK(cv);
-            if (cv.base) {
-                hipEvent_t pe = c.prof_begin(stream);
-                hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((2 * nwin + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS), 0, stream,
-                                   (const void *)in, n, n, 1u, nwin, (void *)out);
-                c.prof_end("msm_group_sum_kernel", pe, stream);
-            }
+            if (cv.base) launch_group_sum(in, n, n, 1u, nwin, out, stream);
             *A_out = out;
             *S_out = cv.base ? out + PB * nwin : nullptr;
             return LW_OK;
@@ -406,12 +470,7 @@ struct MsmRunner {
         const uint32_t ng = (n + g - 1) / g;
         char *lvl = (char *)cv.take(PB * 2 * (size_t)nwin * ng);
         LW_MSM_WS_CHECK(cv);
-        if (cv.base) {
-            hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_group_sum_kernel<C>), dim3((uint32_t)((2 * (uint64_t)ng * nwin + MSM_THREADS - 1) / MSM_THREADS)),
-                               dim3(MSM_THREADS), 0, stream, (const void *)in, n, g, ng, nwin, (void *)lvl);   // two lanes per group
-            c.prof_end("msm_group_sum_kernel", pe, stream);
-        }
+        if (cv.base) launch_group_sum(in, n, g, ng, nwin, lvl, stream);
         char *S2, *A2;
         int rc = reduce(lvl, ng, 2 * nwin, cv, &S2, &A2, stream);
         if (rc) return rc;
@@ -419,7 +478,12 @@ struct MsmRunner {
         LW_MSM_WS_CHECK(cv);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2, MSM_G_LOG, nwin, (void *)S, (void *)A);
+            if (msm_quad_max_lanes())
+                hipLaunchKernelGGL((msm_combine_quad_kernel<C>), dim3((4 * nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2,
+                                   MSM_G_LOG, nwin, (void *)S, (void *)A);
+            else
+                hipLaunchKernelGGL((msm_combine_kernel<C>), dim3((nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2, MSM_G_LOG,
+                                   nwin, (void *)S, (void *)A);
             c.prof_end("msm_combine_kernel", pe, stream);
         }
         *S_out = S;
