@@ -11,6 +11,8 @@
 // leaves HBM and no permuted / row-major copy is materialised.
 // Keccak-256 comes from the `sha3` crate (0.10) in the reference; this is the published Keccak-f[1600] with rate 136
 // and the original 0x01..0x80 padding.
+#include <algorithm>
+#include <stdlib.h>
 #include "context.h"
 
 namespace lw {
@@ -79,6 +81,37 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&st)[25]) {
     for (int i = 0; i < 25; i++) st[i] = ((uint64_t)a[i].hi << 32) | a[i].lo;
 }
 
+// parent k of the level starting at new_begin from its two children in the level starting at level_begin
+__device__ __forceinline__ void merkle_parent(uint64_t *nodes, uint64_t level_begin, uint64_t new_begin, uint64_t k) {
+    const uint64_t *ch = nodes + (level_begin + 2 * k) * 4;
+    uint64_t st[25];
+#pragma unroll
+    for (int j = 0; j < 8; j++) st[j] = ch[j];
+    st[8] = 0x01ull;
+#pragma unroll
+    for (int j = 9; j < 25; j++) st[j] = 0;
+    st[16] = 0x8000000000000000ull;
+    keccak_f1600(st);
+    uint64_t *out = nodes + (new_begin + k) * 4;
+    out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+}
+
+// `levels` levels of the subtree a workgroup owns: its 2 * cnt children in the level starting at level_begin (children
+// [2 * cnt * blockIdx.x, ...) of that level) -> cnt parents, cnt / 2 grandparents, ... with a barrier between levels.  The
+// children of every step but the first were written by this workgroup a moment ago and are read back through L2
+// (a launch per level costs ~10 us of dependent-launch latency on top of a kernel that is a few us long near the top of a
+// tree; the FRI commit phase builds twenty trees per proof).
+__device__ __forceinline__ void merkle_subtree(uint64_t *nodes, uint64_t level_begin, uint32_t cnt, uint32_t levels) {
+    for (uint32_t lv = 0; lv < levels; lv++) {
+        const uint64_t new_begin = level_begin / 2;
+        if (threadIdx.x < cnt) merkle_parent(nodes, level_begin, new_begin, (uint64_t)blockIdx.x * cnt + threadIdx.x);
+        __threadfence_block();   // workgroup scope: an agent-scope release writes back the whole L2 of the XCD (measured: leaf kernel 0.8 -> 13 ms)
+        __syncthreads();
+        level_begin = new_begin;
+        cnt >>= 1;
+    }
+}
+
 // one work-item per leaf; columns[c] starts at cols + c * col_stride elements.  EB = bytes per element as the reference keeps
 // it in memory; as_bytes of an element is its raw (Montgomery) value big-endian:
 //   32: MontgomeryBackendPrimeField<_, 4>, four u64 limbs most significant first (montgomery_backed_prime_fields.rs:367-373)
@@ -86,10 +119,10 @@ __device__ __forceinline__ void keccak_f1600(uint64_t (&st)[25]) {
 //    4: U32MontgomeryBackendPrimeField (BabyBear u32), value().to_be_bytes() (u32_montgomery_backend_prime_field.rs:258-262)
 template <int EB>
 __global__ __launch_bounds__(256) void merkle_leaves_kernel(const void *cols_v, uint32_t n_cols, uint64_t col_stride, uint32_t log2n,
-                                                            int bit_reverse, uint64_t *nodes) {
+                                                            int bit_reverse, uint64_t *nodes, uint32_t fused_levels) {
     const uint64_t n = 1ull << log2n;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) return;   // (whole workgroups only when fused_levels != 0: n is then a multiple of 256)
     const uint64_t src = bit_reverse ? (log2n ? (uint64_t)(__brevll(i) >> (64 - log2n)) : 0) : i;
     const uint32_t total_bytes = (uint32_t)EB * n_cols;
     const uint32_t total = total_bytes / 8;         // whole 8-byte lanes of leaf data
@@ -129,23 +162,17 @@ __global__ __launch_bounds__(256) void merkle_leaves_kernel(const void *cols_v, 
     }
     uint64_t *out = nodes + (n - 1 + i) * 4;
     out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+    if (fused_levels) {   // the first levels above this workgroup's 256 leaves
+        __threadfence_block();   // workgroup scope: an agent-scope release writes back the whole L2 of the XCD (measured: leaf kernel 0.8 -> 13 ms)
+        __syncthreads();
+        merkle_subtree(nodes, n - 1, 128, fused_levels);
+    }
 }
 
-// parents [new_begin, new_begin + count) from children starting at level_begin
-__global__ __launch_bounds__(256) void merkle_level_kernel(uint64_t *nodes, uint64_t level_begin, uint64_t new_begin, uint64_t count) {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    const uint64_t *ch = nodes + (level_begin + 2 * k) * 4;
-    uint64_t st[25];
-#pragma unroll
-    for (int j = 0; j < 8; j++) st[j] = ch[j];
-    st[8] = 0x01ull;
-#pragma unroll
-    for (int j = 9; j < 25; j++) st[j] = 0;
-    st[16] = 0x8000000000000000ull;
-    keccak_f1600(st);
-    uint64_t *out = nodes + (new_begin + k) * 4;
-    out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
+// `levels` levels per launch: a workgroup turns 512 children of the level starting at level_begin into 256 parents, 128
+// grandparents, ...; the level must hold a multiple of 512 nodes
+__global__ __launch_bounds__(256) void merkle_levels_kernel(uint64_t *nodes, uint64_t level_begin, uint32_t levels) {
+    merkle_subtree(nodes, level_begin, 256, levels);
 }
 
 // The top of the tree in one launch: all levels from `count` <= 256 parents down to the root, one workgroup, a barrier
@@ -154,20 +181,8 @@ __global__ __launch_bounds__(256) void merkle_top_kernel(uint64_t *nodes, uint64
     while (level_begin != level_end) {
         const uint64_t new_begin = level_begin / 2, count = level_begin - new_begin;
         const uint64_t k = threadIdx.x;
-        if (k < count) {
-            const uint64_t *ch = nodes + (level_begin + 2 * k) * 4;
-            uint64_t st[25];
-#pragma unroll
-            for (int j = 0; j < 8; j++) st[j] = ch[j];
-            st[8] = 0x01ull;
-#pragma unroll
-            for (int j = 9; j < 25; j++) st[j] = 0;
-            st[16] = 0x8000000000000000ull;
-            keccak_f1600(st);
-            uint64_t *out = nodes + (new_begin + k) * 4;
-            out[0] = st[0]; out[1] = st[1]; out[2] = st[2]; out[3] = st[3];
-        }
-        __threadfence_block();
+        if (k < count) merkle_parent(nodes, level_begin, new_begin, k);
+        __threadfence_block();   // workgroup scope: an agent-scope release writes back the whole L2 of the XCD (measured: leaf kernel 0.8 -> 13 ms)
         __syncthreads();
         level_end = level_begin - 1;
         level_begin = new_begin;
@@ -178,33 +193,41 @@ __global__ __launch_bounds__(256) void merkle_top_kernel(uint64_t *nodes, uint64
 int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64_t col_stride, uint32_t log2n, int bit_reverse,
                          void *d_nodes, hipStream_t stream, uint32_t elem_bytes) {
     const uint64_t n = 1ull << log2n;
+    // Levels per launch (LW_HIP_MERKLE_FUSE, tuning: 1 = a launch per level as before): the tree above 2^m nodes is built
+    // by the top kernel once m <= 9 (256 parents), by launches of up to `fuse` levels before that, the first of them inside
+    // the leaf kernel.
+    static const uint32_t fuse = [] { const char *e = tuning_env("LW_HIP_MERKLE_FUSE"); int v = e ? atoi(e) : 4; return (uint32_t)(v < 1 ? 1 : (v > 7 ? 7 : v)); }();
+    // Wide levels are bound by the hashes' throughput and take a launch each (in a fused launch the upper levels of a
+    // subtree run on 128, 64, 32 ... of the workgroup's 256 work-items while its other waves hold their slots: 1 x 2^24
+    // 4.19 -> 4.35 ms fused everywhere); from 2^16 nodes down a level is a few microseconds long and the launches count.
+    constexpr uint32_t FUSE_BELOW = 16;
+    uint32_t m = log2n;   // the level whose parents are built next holds 2^m nodes
+    const uint32_t leaf_fused = (fuse > 1 && m > 9 && m <= FUSE_BELOW) ? std::min(fuse, m - 9) : 0u;
     hipEvent_t pe = c.prof_begin(stream);
     const dim3 grid((uint32_t)((n + 255) / 256));
     if (elem_bytes == 4)
-        hipLaunchKernelGGL((merkle_leaves_kernel<4>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+        hipLaunchKernelGGL((merkle_leaves_kernel<4>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes, leaf_fused);
     else if (elem_bytes == 8)
-        hipLaunchKernelGGL((merkle_leaves_kernel<8>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+        hipLaunchKernelGGL((merkle_leaves_kernel<8>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes, leaf_fused);
     else
-        hipLaunchKernelGGL((merkle_leaves_kernel<32>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes);
+        hipLaunchKernelGGL((merkle_leaves_kernel<32>), grid, dim3(256), 0, stream, d_cols, n_cols, col_stride, log2n, bit_reverse, (uint64_t *)d_nodes, leaf_fused);
     c.prof_end("merkle_leaves_kernel", pe, stream);
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
-    // crypto/src/merkle_tree/utils.rs:44-72
-    uint64_t level_begin = n - 1, level_end = 2 * level_begin;
-    while (level_begin != level_end) {
-        const uint64_t new_begin = level_begin / 2;
-        const uint64_t count = level_begin - new_begin;
-        if (count <= 256) {   // the rest of the tree in one launch
-            pe = c.prof_begin(stream);
-            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, (uint64_t *)d_nodes, level_begin, level_end);
-            c.prof_end("merkle_top_kernel", pe, stream);
-            break;
-        }
+    m -= leaf_fused;
+    // crypto/src/merkle_tree/utils.rs:44-72: the level of 2^m nodes starts at node 2^m - 1
+    while (m > 9) {
+        const uint32_t lv = m <= FUSE_BELOW ? std::min(fuse, m - 9) : 1u;
         pe = c.prof_begin(stream);
-        hipLaunchKernelGGL(merkle_level_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (uint64_t *)d_nodes,
-                           level_begin, new_begin, count);
+        hipLaunchKernelGGL(merkle_levels_kernel, dim3((uint32_t)(((uint64_t)1 << m) / 512)), dim3(256), 0, stream, (uint64_t *)d_nodes,
+                           ((uint64_t)1 << m) - 1, lv);
         c.prof_end("merkle_level_kernel", pe, stream);
-        level_end = level_begin - 1;
-        level_begin = new_begin;
+        m -= lv;
+    }
+    if (m > 0) {   // the rest of the tree in one launch: at most 256 parents
+        const uint64_t level_begin = ((uint64_t)1 << m) - 1;
+        pe = c.prof_begin(stream);
+        hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, (uint64_t *)d_nodes, level_begin, 2 * level_begin);
+        c.prof_end("merkle_top_kernel", pe, stream);
     }
     LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
     return LW_OK;

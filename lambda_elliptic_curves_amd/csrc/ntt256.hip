@@ -227,10 +227,19 @@ static int power_tables(Context &c, int field, int slot, const uint32_t *base_wo
             return LW_ERR_INV_ZERO;
         }
         if (invert) b = fe_inv<F>(b);
-        LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);   // previous users of the cached tables
-        Fe<F> ninv = fe_inv<F>(fe_from_u64<F>(1ull << (hbits + hi_bits)));   // N^-1 folded into the high table
-        int rc = upload_power_tables<F>(b, hbits, 1ull << hi_bits, cc.lo, cc.hi, fold_ninv ? &ninv : nullptr);
-        if (rc) return rc;
+        // The tables are rebuilt by a kernel on the call's stream, behind their previous users (calls of one lane are
+        // ordered across streams by Entry); growing a buffer frees the old one, which the runtime does synchronously.
+        const uint64_t lo_count = 1ull << hbits, hi_count = 1ull << hi_bits;
+        if (cc.lo.ensure(lo_count * 32) || cc.hi.ensure(hi_count * 32)) return LW_ERR_ALLOC;
+        FeWords8 bw{}, sw{};
+        for (int i = 0; i < 8; i++) bw.w[i] = b.v[i];
+        if (fold_ninv) {   // N^-1 folded into the high table
+            const Fe<F> ninv = fe_inv<F>(fe_from_u64<F>(1ull << (hbits + hi_bits)));
+            for (int i = 0; i < 8; i++) sw.w[i] = ninv.v[i];
+        }
+        hipLaunchKernelGGL((power_tables_kernel<F>), dim3((uint32_t)((lo_count + hi_count + 255) / 256)), dim3(256), 0, stream, (uint4 *)cc.lo.p,
+                           (uint4 *)cc.hi.p, bw, hbits, hi_count, sw, fold_ninv ? 1 : 0);
+        LW_HIP_CHECK(hipGetLastError(), LW_ERR_LAUNCH);
         cc.valid = true;
         cc.fold_ninv = fold_ninv;
         cc.field = field;

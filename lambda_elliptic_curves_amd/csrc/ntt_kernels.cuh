@@ -404,4 +404,35 @@ __global__ void twiddle_fill_kernel(uint4 *tw, const uint4 *lo, const uint4 *hi,
     tw_store<F>(tw, g, fe_mul<F>(a, b));
 }
 
+// The two power tables of a coset offset on the device: lo[i] = base^i (i < 2^hbits), hi[j] = scale * base^(j * 2^hbits)
+// (j < hi_count), one square-and-multiply per entry — a few thousand work-items, nothing uploaded, nothing to wait for.
+// (Built on the host and uploaded, a new offset cost a stream synchronisation, ~3000 serial products and two copies:
+// ~110 us per call, every layer of a FRI commit phase.)
+struct FeWords8 {
+    uint32_t w[8];
+};
+template <class F>
+__global__ void power_tables_kernel(uint4 *lo, uint4 *hi, FeWords8 base, uint32_t hbits, uint64_t hi_count, FeWords8 scale, int has_scale) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo_count = 1ull << hbits;
+    if (t >= lo_count + hi_count) return;
+    const bool is_lo = t < lo_count;
+    const uint64_t e = is_lo ? t : ((t - lo_count) << hbits);
+    Fe<F> b, r = Fe<F>::one();
+#pragma unroll
+    for (int k = 0; k < 8; k++) b.v[k] = base.w[k];
+    for (int bit = 63 - (e ? __clzll((long long)e) : 63); bit >= 0; bit--) {
+        r = fe_sqr<F>(r);
+        if ((e >> bit) & 1) r = fe_mul<F>(r, b);
+    }
+    if (!is_lo && has_scale) {
+        Fe<F> sc;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sc.v[k] = scale.w[k];
+        r = fe_mul<F>(r, sc);
+    }
+    if (is_lo) tw_store<F>(lo, t, r);
+    else tw_store<F>(hi, t - lo_count, r);
+}
+
 }  // namespace lw
