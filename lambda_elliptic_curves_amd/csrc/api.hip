@@ -928,6 +928,16 @@ static uint32_t commit_elem_bytes(lw_field_t field, lw_layout_t layout) {
     if (layout == LW_LAYOUT_EXT4_INTERLEAVED) { set_error("the quartic extension has no AsBytes in the reference (quartic_babybear.rs)"); return 0; }
     return (uint32_t)lw_hip_field_elem_bytes(field, layout);
 }
+// A Merkle root for the caller's transcript: through the lane's pinned words (a 32-byte copy into pageable memory goes
+// through the runtime's staging path, ~2x the latency; FRI reads one root per layer with the GPU idle meanwhile)
+static int read_root(Context &c, const void *d_nodes, uint8_t *out_root, hipStream_t s) {
+    if (!c.pinned_words) LW_HIP_CHECK(hipHostMalloc((void **)&c.pinned_words, 256, hipHostMallocDefault), LW_ERR_ALLOC);
+    uint32_t *stage = c.pinned_words + 32;   // words 0..31: the MSM's small results (msm_core.cuh)
+    LW_HIP_CHECK(hipMemcpyAsync(stage, d_nodes, 32, hipMemcpyDeviceToHost, s), LW_ERR_LAUNCH);
+    LW_HIP_CHECK(hipStreamSynchronize(s), LW_ERR_LAUNCH);
+    memcpy(out_root, stage, 32);
+    return LW_OK;
+}
 int lw_stark_commit_columns_layout_device(lw_field_t field, lw_layout_t layout, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems,
                                           uint32_t log2n, int bit_reverse, void *d_nodes, uint8_t *out_root, void *hip_stream) {
     const uint32_t eb = commit_elem_bytes(field, layout);
@@ -941,10 +951,7 @@ int lw_stark_commit_columns_layout_device(lw_field_t field, lw_layout_t layout, 
     if (col_stride_elems == 0) col_stride_elems = 1ull << log2n;
     int rc = merkle_commit_device(c, d_columns, n_cols, col_stride_elems, log2n, bit_reverse, d_nodes, (hipStream_t)hip_stream, eb);
     if (rc) return rc;
-    if (out_root) {
-        LW_HIP_CHECK(hipMemcpyAsync(out_root, d_nodes, 32, hipMemcpyDeviceToHost, (hipStream_t)hip_stream), LW_ERR_LAUNCH);
-        LW_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream), LW_ERR_LAUNCH);
-    }
+    if (out_root) return read_root(c, d_nodes, out_root, (hipStream_t)hip_stream);
     return LW_OK;
 }
 int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint32_t n_cols, uint64_t col_stride_elems, uint32_t log2n,
@@ -959,10 +966,7 @@ int lw_stark_commit_columns_device(lw_field_t field, const void *d_columns, uint
     if (col_stride_elems == 0) col_stride_elems = 1ull << log2n;
     rc = merkle_commit_device(c, d_columns, n_cols, col_stride_elems, log2n, bit_reverse, d_nodes, (hipStream_t)hip_stream);
     if (rc) return rc;
-    if (out_root) {
-        LW_HIP_CHECK(hipMemcpyAsync(out_root, d_nodes, 32, hipMemcpyDeviceToHost, (hipStream_t)hip_stream), LW_ERR_LAUNCH);
-        LW_HIP_CHECK(hipStreamSynchronize((hipStream_t)hip_stream), LW_ERR_LAUNCH);
-    }
+    if (out_root) return read_root(c, d_nodes, out_root, (hipStream_t)hip_stream);
     return LW_OK;
 }
 
@@ -1063,10 +1067,7 @@ int lw_stark_fri_layer_device(lw_field_t field, const void *d_coeffs, size_t n_c
     int rc = fri_layer_device(c, field, d_coeffs, n_coeffs, zw, coset_offset, lgd, d_out_poly, lgb, layer ? c.pipe_tmp.p : nullptr,
                               d_out_evaluation_or_null, d_nodes_or_null, en.stream);
     if (rc) return rc;
-    if (out_root_or_null) {
-        LW_HIP_CHECK(hipMemcpyAsync(out_root_or_null, d_nodes_or_null, 32, hipMemcpyDeviceToHost, en.stream), LW_ERR_LAUNCH);
-        LW_HIP_CHECK(hipStreamSynchronize(en.stream), LW_ERR_LAUNCH);
-    }
+    if (out_root_or_null) return read_root(c, d_nodes_or_null, out_root_or_null, en.stream);
     return LW_OK;
 }
 
