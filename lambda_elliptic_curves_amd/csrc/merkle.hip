@@ -121,8 +121,15 @@ template <int EB>
 __global__ __launch_bounds__(256) void merkle_leaves_kernel(const void *cols_v, uint32_t n_cols, uint64_t col_stride, uint32_t log2n,
                                                             int bit_reverse, uint64_t *nodes, uint32_t fused_levels) {
     const uint64_t n = 1ull << log2n;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;   // (whole workgroups only when fused_levels != 0: n is then a multiple of 256)
+    // Bit-reversed gather of a large tree: work-item i reading row bitrev(i) makes every 32-byte read of a wave land 2^(n-8)
+    // rows from the next.  Leaves are handed out in 16 x 16 tiles instead — i = u * 2^(n-4) + M * 16 + v for the
+    // workgroup M and tid = 16 u + v — so that the rows of a fixed v are 16 consecutive ones (bitrev(i) ends in bitrev4(u))
+    // and the leaves of a fixed u are 16 consecutive ones: reads and writes both in 512-byte runs.  (Trees with fused
+    // levels keep consecutive leaves per workgroup.)
+    if (bit_reverse && fused_levels == 0 && log2n >= 12)
+        i = ((uint64_t)(threadIdx.x >> 4) << (log2n - 4)) | ((uint64_t)blockIdx.x << 4) | (threadIdx.x & 15);
     const uint64_t src = bit_reverse ? (log2n ? (uint64_t)(__brevll(i) >> (64 - log2n)) : 0) : i;
     const uint32_t total_bytes = (uint32_t)EB * n_cols;
     const uint32_t total = total_bytes / 8;         // whole 8-byte lanes of leaf data
