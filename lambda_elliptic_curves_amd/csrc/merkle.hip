@@ -127,9 +127,12 @@ __global__ __launch_bounds__(256) void merkle_leaves_kernel(const void *cols_v, 
     // rows from the next.  Leaves are handed out in 16 x 16 tiles instead — i = u * 2^(n-4) + M * 16 + v for the
     // workgroup M and tid = 16 u + v — so that the rows of a fixed v are 16 consecutive ones (bitrev(i) ends in bitrev4(u))
     // and the leaves of a fixed u are 16 consecutive ones: reads and writes both in 512-byte runs.  (Trees with fused
-    // levels keep consecutive leaves per workgroup.)
-    if (bit_reverse && fused_levels == 0 && log2n >= 12)
-        i = ((uint64_t)(threadIdx.x >> 4) << (log2n - 4)) | ((uint64_t)blockIdx.x << 4) | (threadIdx.x & 15);
+    // levels keep consecutive leaves per workgroup.)  The host asks for it with bit_reverse = 2.
+    // Narrow elements take wider tiles on the read side: 2^UB rows x 2^(8-UB) leaves with UB = 4 / 5 / 6 for 32- / 8- /
+    // 4-byte elements (512 / 256 / 256-byte runs of rows per column, 512 / 256 / 128-byte runs of leaf hashes).
+    constexpr int UB = EB == 32 ? 4 : (EB == 8 ? 5 : 6), VB = 8 - UB;
+    if (bit_reverse == 2)
+        i = ((uint64_t)(threadIdx.x >> VB) << (log2n - UB)) | ((uint64_t)blockIdx.x << VB) | (threadIdx.x & ((1u << VB) - 1));
     const uint64_t src = bit_reverse ? (log2n ? (uint64_t)(__brevll(i) >> (64 - log2n)) : 0) : i;
     const uint32_t total_bytes = (uint32_t)EB * n_cols;
     const uint32_t total = total_bytes / 8;         // whole 8-byte lanes of leaf data
@@ -210,6 +213,8 @@ int merkle_commit_device(Context &c, const void *d_cols, uint32_t n_cols, uint64
     constexpr uint32_t FUSE_BELOW = 16;
     uint32_t m = log2n;   // the level whose parents are built next holds 2^m nodes
     const uint32_t leaf_fused = (fuse > 1 && m > 9 && m <= FUSE_BELOW) ? std::min(fuse, m - 9) : 0u;
+    static const bool tile_env = [] { const char *e = tuning_env("LW_HIP_MERKLE_TILE"); return !e || atoi(e) != 0; }();   // A/B only
+    if (bit_reverse) bit_reverse = (tile_env && leaf_fused == 0 && log2n >= 12) ? 2 : 1;
     hipEvent_t pe = c.prof_begin(stream);
     const dim3 grid((uint32_t)((n + 255) / 256));
     if (elem_bytes == 4)
