@@ -735,8 +735,9 @@ uint32_t msm_g_log() {
     return g;
 }
 uint64_t msm_quad_max_lanes() {   // tuning: LW_HIP_MSM_QUAD = log2 of the widest level (in lanes) that takes the quad kernels, 0 = none
-    static uint64_t m = [] { const char *e = tuning_env("LW_HIP_MSM_QUAD"); int v = e ? atoi(e) : 18; return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 30 ? 30 : v); }();
-    return m;
+    const char *e = tuning_env("LW_HIP_MSM_QUAD");   // read per call so that a test can sweep it
+    const int v = e ? atoi(e) : 18;
+    return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 30 ? 30 : v);
 }
 int msm_waves_per_simd() {
     static int w = [] { const char *e = tuning_env("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();

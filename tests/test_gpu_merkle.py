@@ -8,7 +8,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 1), (1, 6), (2, 3), (4, 10), (5, 7), (17, 5), (34, 4), (3, 14)])
+# 2^10 .. 2^16: levels fused into the leaf kernel and four per launch (1 - 4 of them); 2^17: the tiled bit-reversed gather
+@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 1), (1, 6), (2, 3), (4, 10), (5, 7), (17, 5), (34, 4), (3, 14), (1, 9), (2, 11), (1, 12),
+                                          (1, 13), (2, 16), (2, 17), (5, 18)])
 def test_commit_matches_oracle(n_cols, log_n):
     from lambda_elliptic_curves_amd import fft, merkle
     n = 1 << log_n
@@ -63,7 +65,7 @@ def test_fri_layer_matches_reference_composition(n_coeffs, domain):
 
 
 @pytest.mark.parametrize("name", ["babybear_u32", "babybear_u64"])
-@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 3), (3, 5), (4, 10), (33, 6), (35, 4), (17, 9)])
+@pytest.mark.parametrize("n_cols,log_n", [(1, 0), (1, 3), (3, 5), (4, 10), (33, 6), (35, 4), (17, 9), (3, 13), (3, 17), (4, 18)])
 def test_babybear_commit_matches_oracle(name, n_cols, log_n):
     """The commitment over BabyBear columns (BASELINE config 4's field): leaves hash the raw words big-endian, 4 or 8 bytes per
     element; odd u32 column counts leave half a Keccak lane before the padding, 35 columns span two blocks."""

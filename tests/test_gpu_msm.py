@@ -252,6 +252,26 @@ def test_msm_every_window_width_matches_oracle(name, n, monkeypatch):
         assert aff(oid, got) == exp, f"window width {c}"
 
 
+@pytest.mark.parametrize("name,n", [("bls12_381_g1", 5000), ("bn254_g1", 3000), ("bn254_g2", 700), ("bls12_381_g2", 500)])
+def test_msm_bucket_reduce_pair_and_quad_kernels_agree_with_oracle(name, n, monkeypatch):
+    """The running sums over the buckets (pippenger.rs:85-98) are hierarchical; a level runs on two lanes per group or — where
+    the chain of dependent additions is all there is — on eight, with every complete addition spread over a quad of lanes
+    (msm_group_sum_quad_kernel, ec.cuh pt_add_quad: doublings as p + p, the identity as an operand, partial last groups).
+    LW_HIP_MSM_QUAD = log2 of the widest level in lanes that takes the quad kernels (read per call): none, the default, all
+    of them; window widths whose bucket count is and is not a multiple of the group size."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    scalars, points = util.msm_case(oid, n, 7100 + n)
+    scalars[5] = 0                       # empty contribution
+    scalars[6:9] = scalars[9:12]         # repeated scalars on different points
+    exp = aff(oid, O.parallel_msm_with(oid, scalars, points, 8, 16))
+    for c in (5, 8, 11, 16):
+        monkeypatch.setenv("LW_HIP_MSM_C", str(c))
+        for q in ("0", "18", "30"):
+            monkeypatch.setenv("LW_HIP_MSM_QUAD", q)
+            assert aff(oid, msm.msm(crv, scalars, points)) == exp, f"c = {c}, quad = {q}"
+
+
 def test_msm_wide_windows_at_scale_match_oracle(monkeypatch):
     """c = 20 (the width used from 2^23 points, 64-bit items, 512 coarse bins x 1024 keys) and c = 19 on 2^17 points: buckets of
     ~0.25 items, the short-top-window path with multi-round partial sums, and the ordered piece dispatch."""
