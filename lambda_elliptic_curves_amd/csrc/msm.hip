@@ -647,7 +647,10 @@ size_t msm_order_tmp_bytes() { return 8 * ORDER_BINS; }
 uint32_t msm_ch(uint64_t items) {
     static const int env = [] { const char *e = tuning_env("LW_HIP_MSM_CH"); return e ? atoi(e) : 0; }();
     if (env) return (uint32_t)(env < 4 ? 4 : (env > 128 ? 128 : env));
-    return items < (1ull << 22) ? 16u : items < (1ull << 27) ? 32u : 64u;
+    // below 2^20 items (c = 8: fewer than 2^15 points) a second round of short chains beats one of long ones: 2^10 0.95 ->
+    // 0.82 ms, 2^12 0.98 -> 0.90, 2^14 1.35 -> 1.15 at 8 (4 is no better); 2^16 (c = 16, 2^20.1 items) keeps 16: 1.47 ms
+    // against 1.53 at 8 (tools/ab_msm_ch_small.sh, profiles/r03_ab_msm_ch_small.txt)
+    return items < (1ull << 20) ? 8u : items < (1ull << 22) ? 16u : items < (1ull << 27) ? 32u : 64u;
 }
 int msm_piece_order_enabled() {
     static int v = [] { const char *e = tuning_env("LW_HIP_MSM_ORDER"); return e ? atoi(e) : 1; }();
