@@ -43,6 +43,22 @@ def test_ntt_reproduces_survey_anchor_vectors(kats):
     assert O.elems_from_mont(f, n_inv) == [pow(4, -1, 0x800000000000011000000000000000000000000000000000000000000000001)] * 4
 
 
+@pytest.mark.parametrize("name", ["stark252", "fr381", "babybear_u64", "babybear_u32"])
+def test_compose_fft_fixed_case(name):
+    """composition_fft_works (fft/polynomial.rs:346-354): compose_fft(2x, x^3) == 2x^3 through the HIP evaluate_fft /
+    interpolate_fft (the reference's own fixed case for this API; field-independent identity)."""
+    fld, oid = util.field_pairs()[name]
+    p = util.field_modulus(name)
+    ev = O.elems_from_mont(oid, fft_mod().evaluate_fft(fld, O.elems_to_mont(oid, [0, 0, 0, 1])))
+    vals = O.elems_to_mont(oid, [2 * v % p for v in ev])
+    assert O.elems_from_mont(oid, fft_mod().interpolate_fft(fld, vals)) == [0, 0, 0, 2]
+
+
+def fft_mod():
+    from lambda_elliptic_curves_amd import fft
+    return fft
+
+
 def test_bit_reverse_table_16(kats):
     from lambda_elliptic_curves_amd import fft
     arr = O.elems_to_mont(O.F_BABYBEAR_U32, list(range(16)))

@@ -165,3 +165,15 @@ def test_ext4_values_over_base_domain():
     assert g == [exp_cols[k][i] for i in range(len(exp_cols[0])) for k in range(4)]
     ev = O.evaluate_fft(O.F_BABYBEAR_EXT4, arr)
     assert np.array_equal(O.interpolate_fft(O.F_BABYBEAR_EXT4, ev), arr)
+
+
+@pytest.mark.parametrize("field,p", NTT_FIELDS)
+def test_compose_fft_fixed_case(field, p):
+    """composition_fft_works (fft/polynomial.rs:346-354): compose_fft(p = 2x, q = x^3) == 2x^3, i.e. evaluate_fft(q), p applied
+    pointwise, interpolate_fft (compose_fft, :130-146).  The reference runs it over its u64 test field; the identity holds in
+    every field, so it pins evaluate -> interpolate here the same way."""
+    q = O.elems_to_mont(field, [0, 0, 0, 1])
+    ev = O.elems_from_mont(field, O.evaluate_fft(field, q))
+    vals = O.elems_to_mont(field, [2 * v % p for v in ev])            # p(x) = 2x at q's evaluations
+    assert O.elems_from_mont(field, O.interpolate_fft(field, vals)) == [0, 0, 0, 2]
+

@@ -18,6 +18,11 @@ def field_pairs():
 P_BABYBEAR = 2013265921
 
 
+def field_modulus(name):
+    from oracle import bigint_def as D
+    return {"stark252": D.P_STARK252, "fr381": D.P_FR381}.get(name, P_BABYBEAR)
+
+
 def rand_elems(name, n, seed):
     """n canonical residues (any value < p is a valid Montgomery-form element), reference layout."""
     rng = np.random.default_rng(seed)
