@@ -739,7 +739,8 @@ uint32_t msm_g_log() {
 }
 uint64_t msm_quad_max_lanes() {   // tuning: LW_HIP_MSM_QUAD = log2 of the widest level (in lanes) that takes the quad kernels, 0 = none
     const char *e = tuning_env("LW_HIP_MSM_QUAD");   // read per call so that a test can sweep it
-    const int v = e ? atoi(e) : 18;
+    if (!e) return ~(uint64_t)0;                     // not set: the group's own default (msm_core.cuh launch_group_sum)
+    const int v = atoi(e);
     return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 30 ? 30 : v);
 }
 int msm_waves_per_simd() {

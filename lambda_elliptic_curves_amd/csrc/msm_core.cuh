@@ -11,7 +11,7 @@ namespace lw {
 
 uint32_t msm_ch(uint64_t items);       // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
 int msm_piece_order_enabled();         // LW_HIP_MSM_ORDER=0: work-items take their pieces in key order (A/B)
-uint64_t msm_quad_max_lanes();          // levels of the bucket reduce with at most this many lanes (8 per group) spread each addition over a quad; 0 = never
+uint64_t msm_quad_max_lanes();          // LW_HIP_MSM_QUAD: levels of the bucket reduce with at most this many lanes (8 per group) spread each addition over a quad; 0 = never, ~0 = not set
 uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
@@ -444,8 +444,13 @@ struct MsmRunner {
     // each addition spread over a quad (msm_group_sum_quad_kernel).
     void launch_group_sum(const char *in, uint32_t n, uint32_t g, uint32_t ng, uint32_t nwin, char *out, hipStream_t stream) {
         const uint64_t groups = (uint64_t)ng * nwin;
+        // widest level on the quad kernel: 2^18 lanes; 2^20 for BLS12-381 G2, whose pair kernel needs 256 VGPRs (one wave per
+        // SIMD) where the quad kernel needs 192 (tools/ab_msm_quad_g2.py: reduce 2.30 -> 2.15 ms; the other groups lose 5 %)
+        constexpr uint64_t QUAD_DEFAULT = (uint64_t)1 << (std::is_same<typename C::B, Fp2Ops<Fp381>>::value ? 20 : 18);
+        const uint64_t quad_env = msm_quad_max_lanes();
+        const uint64_t quad_max = quad_env == ~(uint64_t)0 ? QUAD_DEFAULT : quad_env;
         hipEvent_t pe = c.prof_begin(stream);
-        if (8 * groups <= msm_quad_max_lanes())
+        if (8 * groups <= quad_max)
             hipLaunchKernelGGL((msm_group_sum_quad_kernel<C>), dim3((uint32_t)((8 * groups + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0,
                                stream, (const void *)in, n, g, ng, nwin, (void *)out);
         else
@@ -478,7 +483,7 @@ struct MsmRunner {
         LW_MSM_WS_CHECK(cv);
         if (cv.base) {
             hipEvent_t pe = c.prof_begin(stream);
-            if (msm_quad_max_lanes())
+            if (msm_quad_max_lanes() != 0)
                 hipLaunchKernelGGL((msm_combine_quad_kernel<C>), dim3((4 * nwin + 63) / 64), dim3(64), 0, stream, (const void *)S2, (const void *)A2,
                                    MSM_G_LOG, nwin, (void *)S, (void *)A);
             else
