@@ -743,6 +743,11 @@ uint64_t msm_quad_max_lanes() {   // tuning: LW_HIP_MSM_QUAD = log2 of the wides
     const int v = atoi(e);
     return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 30 ? 30 : v);
 }
+uint64_t msm_accumulate_quad_max_lanes() {   // tuning: LW_HIP_MSM_ACCQ = log2 of the widest accumulate launch (in lanes) on the quad kernel, 0 = none; read per call
+    const char *e = tuning_env("LW_HIP_MSM_ACCQ");
+    const int v = e ? atoi(e) : 19;
+    return v <= 0 ? (uint64_t)0 : (uint64_t)1 << (v > 30 ? 30 : v);
+}
 int msm_waves_per_simd() {
     static int w = [] { const char *e = tuning_env("LW_HIP_MSM_WAVES"); int v = e ? atoi(e) : 2; return v == 3 ? 3 : 2; }();
     return w;

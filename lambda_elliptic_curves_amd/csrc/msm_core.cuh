@@ -12,6 +12,7 @@ namespace lw {
 uint32_t msm_ch(uint64_t items);       // max points per accumulate work-item (a bucket is cut into equal pieces <= CH)
 int msm_piece_order_enabled();         // LW_HIP_MSM_ORDER=0: work-items take their pieces in key order (A/B)
 uint64_t msm_quad_max_lanes();          // LW_HIP_MSM_QUAD: levels of the bucket reduce with at most this many lanes (8 per group) spread each addition over a quad; 0 = never, ~0 = not set
+uint64_t msm_accumulate_quad_max_lanes();   // LW_HIP_MSM_ACCQ: accumulate launches of projective rows with at most this many lanes (4 per piece) use the quad kernel
 uint32_t msm_g_log();                  // log2 buckets per running-sum group: 3 (8 buckets; 16 -> 8 saved 1 ms of dependent-add latency per MSM, 4 is no better)
 constexpr int MSM_THREADS = 128;
 
@@ -135,6 +136,71 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
         asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // consume the touches after the MACs
     }
     pt_st<C>(dst, slot, acc);
+}
+
+// The same work-items on four lanes each (projective rows only): when the pieces do not fill the machine a work-item's
+// chain of dependent additions IS the kernel time, so every addition is spread over a quad (pt_add_quad, ec.cuh): lane s
+// gathers, keeps and stores coordinate s only; the next row is fetched one addition ahead.  Same (key, piece) logic, same
+// results up to the projective representative.
+template <class C>
+__global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_quad_kernel(const void *pts, const uint32_t *index, const uint32_t *seg_off,
+                                                                           const uint32_t *out_off, const uint32_t *perm_t,
+                                                                           const uint32_t *perm_key, uint32_t K, uint32_t total_items, void *pout,
+                                                                           void *buckets) {
+    using B = typename C::B;
+    using T = typename B::T;
+    constexpr size_t ROW = 3 * B::BYTES;
+    constexpr uint32_t IDX = 0x7fffffffu;
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = gt >> 2;
+    if (r >= total_items) return;                // quads are never split
+    const uint32_t s = (gt & 3) == 3 ? 0u : (gt & 3);
+    const uint32_t t = perm_t ? perm_t[r] : r;
+    uint32_t b, e;
+    void *dst = buckets;
+    size_t slot = t;
+    if (out_off) {
+        uint32_t lo = 0, hi = K;
+        if (perm_key) {
+            lo = perm_key[r];
+        } else {
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (out_off[mid] <= t) lo = mid; else hi = mid;
+            }
+        }
+        const uint32_t s0 = seg_off[lo], len = seg_off[lo + 1] - s0, np = out_off[lo + 1] - out_off[lo], j = t - out_off[lo];
+        b = s0 + (uint32_t)(((uint64_t)len * j) / np);
+        e = s0 + (uint32_t)(((uint64_t)len * (j + 1)) / np);
+        if (!index && len <= 1) return;
+        if (np == 1) slot = lo; else dst = pout;
+    } else {
+        b = seg_off[t];
+        e = seg_off[t + 1];
+        if (!index && e - b <= 1) return;
+    }
+    const bool ylane = s == 1;
+    auto fetch = [&](uint32_t i, bool &neg) {
+        const uint32_t ix = index ? index[i] : i;
+        neg = index && (ix >> 31) && ylane;
+        return B::load((const char *)pts + (size_t)(ix & IDX) * ROW + s * B::BYTES);
+    };
+    T acc = ylane ? B::one() : B::zero();        // (0 : 1 : 0)
+    if (b < e) {
+        bool neg;
+        acc = fetch(b, neg);
+        acc = B::select(neg, B::neg(acc), acc);
+        T qn = acc;
+        bool negn = false;
+        if (b + 1 < e) qn = fetch(b + 1, negn);
+#pragma nounroll
+        for (uint32_t i = b + 1; i < e; i++) {
+            const T q = B::select(negn, B::neg(qn), qn);
+            if (i + 1 < e) qn = fetch(i + 1, negn);
+            acc = pt_add_quad<C>(acc, q, s);
+        }
+    }
+    if ((gt & 3) != 3) B::store((char *)dst + slot * ROW + s * B::BYTES, acc);
 }
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
@@ -565,7 +631,10 @@ struct MsmRunner {
             if (!hooked) { before_first_launch(); hooked = true; }
             const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(s);
-            if (index && affine)
+            if (!affine && 4 * (uint64_t)total <= msm_accumulate_quad_max_lanes())   // few pieces: their chains are the kernel time
+                hipLaunchKernelGGL((msm_accumulate_quad_kernel<C>), dim3((uint32_t)((4 * (uint64_t)total + MSM_THREADS - 1) / MSM_THREADS)),
+                                   dim3(MSM_THREADS), 0, s, pts, index, seg, out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
+            else if (index && affine)
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, s, pts, index, seg,
                                    out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else if (out_off && C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
