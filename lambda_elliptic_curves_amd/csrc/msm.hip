@@ -645,7 +645,8 @@ size_t msm_order_tmp_bytes() { return 8 * ORDER_BINS; }
 // 32); when the items do not fill the machine a work-item's chain IS the kernel time, so short pieces and one more
 // round win (2^14, c = 8: 1.60 ms at 16, 2.07 at 64).  LW_HIP_MSM_CH: tuning only.
 uint32_t msm_ch(uint64_t items) {
-    static const int env = [] { const char *e = tuning_env("LW_HIP_MSM_CH"); return e ? atoi(e) : 0; }();
+    const char *e = tuning_env("LW_HIP_MSM_CH");   // read per call so that a test can force several rounds of partial sums
+    const int env = e ? atoi(e) : 0;
     if (env) return (uint32_t)(env < 4 ? 4 : (env > 128 ? 128 : env));
     // below 2^20 items (c = 8: fewer than 2^15 points) a second round of short chains beats one of long ones: 2^10 0.95 ->
     // 0.82 ms, 2^12 0.98 -> 0.90, 2^14 1.35 -> 1.15 at 8 (4 is no better); 2^16 (c = 16, 2^20.1 items) keeps 16: 1.47 ms

@@ -270,6 +270,14 @@ def test_msm_bucket_reduce_pair_and_quad_kernels_agree_with_oracle(name, n, monk
         for q in ("0", "18", "30"):
             monkeypatch.setenv("LW_HIP_MSM_QUAD", q)
             assert aff(oid, msm.msm(crv, scalars, points)) == exp, f"c = {c}, quad = {q}"
+        # the accumulation itself on one lane per piece or on four (msm_accumulate_quad_kernel: signed entries, the ordered
+        # dispatch, multi-round partial sums, empty keys), LW_HIP_MSM_ACCQ read per call; short pieces force several rounds
+        monkeypatch.setenv("LW_HIP_MSM_CH", "4")
+        for aq in ("0", "30"):
+            monkeypatch.setenv("LW_HIP_MSM_ACCQ", aq)
+            assert aff(oid, msm.msm(crv, scalars, points)) == exp, f"c = {c}, accq = {aq}"
+        monkeypatch.delenv("LW_HIP_MSM_ACCQ")
+        monkeypatch.delenv("LW_HIP_MSM_CH")
 
 
 def test_msm_wide_windows_at_scale_match_oracle(monkeypatch):
