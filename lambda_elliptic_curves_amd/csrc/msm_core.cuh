@@ -138,18 +138,18 @@ __global__ __launch_bounds__(MSM_THREADS, WAVES) void msm_accumulate_kernel(cons
     pt_st<C>(dst, slot, acc);
 }
 
-// The same work-items on four lanes each (projective rows only): when the pieces do not fill the machine a work-item's
+// The same work-items on four lanes each: when the pieces do not fill the machine a work-item's
 // chain of dependent additions IS the kernel time, so every addition is spread over a quad (pt_add_quad, ec.cuh): lane s
 // gathers, keeps and stores coordinate s only; the next row is fetched one addition ahead.  Same (key, piece) logic, same
 // results up to the projective representative.
-template <class C>
+template <class C, bool AFFINE>
 __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_quad_kernel(const void *pts, const uint32_t *index, const uint32_t *seg_off,
                                                                            const uint32_t *out_off, const uint32_t *perm_t,
                                                                            const uint32_t *perm_key, uint32_t K, uint32_t total_items, void *pout,
                                                                            void *buckets) {
     using B = typename C::B;
     using T = typename B::T;
-    constexpr size_t ROW = 3 * B::BYTES;
+    constexpr size_t ROW = AFFINE ? aff_stride<C>() : 3 * B::BYTES;   // AFFINE: rows of a pre-normalised SRS (first round only)
     constexpr uint32_t IDX = 0x7fffffffu;
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = gt >> 2;
@@ -183,7 +183,15 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_quad_kernel(const 
     auto fetch = [&](uint32_t i, bool &neg) {
         const uint32_t ix = index ? index[i] : i;
         neg = index && (ix >> 31) && ylane;
-        return B::load((const char *)pts + (size_t)(ix & IDX) * ROW + s * B::BYTES);
+        const char *row = (const char *)pts + (size_t)(ix & IDX) * ROW;
+        if constexpr (AFFINE) {   // (x, y) with z = 1 implied; the identity row (0, 0) becomes (0 : 1 : 0)
+            const T v = s < 2 ? B::load(row + s * B::BYTES) : B::one();
+            const int zero = s < 2 && B::is_zero(v);
+            const bool ident = __builtin_amdgcn_mov_dpp(zero, 0x00, 0xF, 0xF, true) & __builtin_amdgcn_mov_dpp(zero, 0x55, 0xF, 0xF, true);
+            return B::select(ident, ylane ? B::one() : B::zero(), v);
+        } else {
+            return B::load(row + s * B::BYTES);
+        }
     };
     T acc = ylane ? B::one() : B::zero();        // (0 : 1 : 0)
     if (b < e) {
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accumulate_quad_kernel(const 
             acc = pt_add_quad<C>(acc, q, s);
         }
     }
-    if ((gt & 3) != 3) B::store((char *)dst + slot * ROW + s * B::BYTES, acc);
+    if ((gt & 3) != 3) B::store((char *)dst + slot * (3 * B::BYTES) + s * B::BYTES, acc);   // partial sums and buckets are projective rows
 }
 
 // SRS preparation: projective rows -> affine pairs with Montgomery's batch inversion (the reference's
@@ -631,10 +639,15 @@ struct MsmRunner {
             if (!hooked) { before_first_launch(); hooked = true; }
             const uint32_t blocks = (total + MSM_THREADS - 1) / MSM_THREADS;
             hipEvent_t pe = c.prof_begin(s);
-            if (!affine && 4 * (uint64_t)total <= msm_accumulate_quad_max_lanes())   // few pieces: their chains are the kernel time
-                hipLaunchKernelGGL((msm_accumulate_quad_kernel<C>), dim3((uint32_t)((4 * (uint64_t)total + MSM_THREADS - 1) / MSM_THREADS)),
-                                   dim3(MSM_THREADS), 0, s, pts, index, seg, out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
-            else if (index && affine)
+            if (4 * (uint64_t)total <= msm_accumulate_quad_max_lanes()) {   // few pieces: their chains are the kernel time
+                const dim3 qgrid((uint32_t)((4 * (uint64_t)total + MSM_THREADS - 1) / MSM_THREADS));
+                if (index && affine)
+                    hipLaunchKernelGGL((msm_accumulate_quad_kernel<C, true>), qgrid, dim3(MSM_THREADS), 0, s, pts, index, seg, out_off, perm_t,
+                                       perm_key, K, total, pout, (void *)buckets);
+                else
+                    hipLaunchKernelGGL((msm_accumulate_quad_kernel<C, false>), qgrid, dim3(MSM_THREADS), 0, s, pts, index, seg, out_off, perm_t,
+                                       perm_key, K, total, pout, (void *)buckets);
+            } else if (index && affine)
                 hipLaunchKernelGGL((msm_accumulate_kernel<C, C::ACC_WAVES, true>), dim3(blocks), dim3(MSM_THREADS), 0, s, pts, index, seg,
                                    out_off, perm_t, perm_key, K, total, pout, (void *)buckets);
             else if (out_off && C::ACC_WAVES == 2 && msm_waves_per_simd() == 3)
