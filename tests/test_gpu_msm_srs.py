@@ -129,6 +129,32 @@ def test_srs_identity_rows_across_batch_inversion_runs(name):
     srs.close()
 
 
+@pytest.mark.parametrize("name", CURVES)
+def test_srs_accumulation_on_one_and_on_four_lanes_per_piece(name, monkeypatch):
+    """Small handles accumulate with every addition spread over a quad of lanes (msm_accumulate_quad_kernel<AFFINE>: lanes 0 / 1
+    gather x / y, an identity row (0, 0) is recognised across the quad), larger ones with one lane per piece and the mixed
+    addition; LW_HIP_MSM_ACCQ (read per call) runs the same handle through both, with identity rows, P / -P, repeated points and
+    pieces short enough for several rounds of partial sums."""
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    n = 600
+    scalars, points = util.msm_case(oid, n, 4100)
+    points = points.copy()
+    for i in (0, 1, 77, n - 1):
+        points[i] = O.ec_neutral(oid)
+    points[11] = points[10]
+    points[13] = O.ec_neg(oid, points[12])
+    scalars[13] = scalars[12]
+    scalars[20:40] = scalars[20]                     # twenty items in the same buckets
+    exp = aff(oid, O.msm(oid, scalars, points))
+    srs = msm.Srs(crv, points)
+    monkeypatch.setenv("LW_HIP_MSM_CH", "4")
+    for aq in ("0", "30"):
+        monkeypatch.setenv("LW_HIP_MSM_ACCQ", aq)
+        assert aff(oid, srs.msm(scalars)) == exp, f"accq = {aq}"
+    srs.close()
+
+
 @pytest.mark.parametrize("name,n", [("bls12_381_g1", 3000), ("bn254_g1", 2000), ("bn254_g2", 700), ("bls12_381_g2", 500)])
 def test_folded_srs_matches_oracle_small(name, n, monkeypatch):
     """Large SRS handles keep W = 13 window-shifted copies (row w*n + i = 2^(20 w) P_i) and sort the signed 20-bit digits of
