@@ -69,9 +69,10 @@ def fri_layer(field, coeffs, zeta, coset_offset, domain_size, return_nodes=False
     return out + (nodes,) if return_nodes else out
 
 
-def fri_layer_device(field, t_coeffs, n_coeffs, zeta, coset_offset, domain_size, want_evaluation=True, stream=None):
+def fri_layer_device(field, t_coeffs, n_coeffs, zeta, coset_offset, domain_size, want_evaluation=True, stream=None, buffers=None):
     """One layer of commit_phase with everything large resident in HBM: returns (t_poly, n_out, t_evaluation, t_nodes, root);
-    t_poly is the zero-padded block holding p' = 2*fold(p, zeta) (the next layer's input), n_out = ceil(n_coeffs/2)."""
+    t_poly is the zero-padded block holding p' = 2*fold(p, zeta) (the next layer's input), n_out = ceil(n_coeffs/2).
+    buffers: (t_poly, t_evaluation_or_None, t_nodes) allocated by the caller (a prover allocates its layers once)."""
     import torch
     if stream is None:
         stream = torch.cuda.current_stream().cuda_stream
@@ -79,9 +80,13 @@ def fri_layer_device(field, t_coeffs, n_coeffs, zeta, coset_offset, domain_size,
     off = np.ascontiguousarray(coset_offset, dtype=np.uint64).reshape(4)
     n_out = (n_coeffs + 1) // 2
     blk = max(2, 1 << (n_out - 1).bit_length())
-    t_poly = torch.empty((blk, 4), dtype=torch.int64, device=t_coeffs.device)
-    t_ev = torch.empty((domain_size, 4), dtype=torch.int64, device=t_coeffs.device) if want_evaluation else None
-    t_nodes = torch.empty(((domain_size - 1) * 4,), dtype=torch.int64, device=t_coeffs.device)
+    if buffers is not None:
+        t_poly, t_ev, t_nodes = buffers
+        want_evaluation = t_ev is not None
+    else:
+        t_poly = torch.empty((blk, 4), dtype=torch.int64, device=t_coeffs.device)
+        t_ev = torch.empty((domain_size, 4), dtype=torch.int64, device=t_coeffs.device) if want_evaluation else None
+        t_nodes = torch.empty(((domain_size - 1) * 4,), dtype=torch.int64, device=t_coeffs.device)
     root = np.zeros(32, np.uint8)
     check(L.lib().lw_stark_fri_layer_device(field.field, C.c_void_p(t_coeffs.data_ptr()), n_coeffs, z.ctypes.data_as(C.c_void_p),
                                             off.ctypes.data_as(C.c_void_p), domain_size, C.c_void_p(t_poly.data_ptr()),
@@ -110,13 +115,23 @@ def fri_commit_phase_device(field, number_layers, t_p0, n_coeffs, sample_zeta, a
     The transcript stays with the caller: sample_zeta() -> FieldElement (4 x u64), append_root(bytes);
     coset_offset_sq(k) -> the k-times squared coset offset as a FieldElement (the caller owns field arithmetic on scalars).
     Returns (t_last_poly, layers) with layers = [(t_evaluation, t_nodes, root, domain_size)]."""
+    import torch
     t_poly, n = t_p0, n_coeffs
     layers = []
+    # every layer's buffers up front (sizes are known: the polynomial halves, the domain halves), as a prover would
+    bufs, nn, dd = [], n_coeffs, domain_size
+    stream = torch.cuda.current_stream().cuda_stream
+    for k in range(1, number_layers):
+        nn, dd = (nn + 1) // 2, dd // 2
+        blk = max(2, 1 << (nn - 1).bit_length())
+        bufs.append((torch.empty((blk, 4), dtype=torch.int64, device=t_p0.device),
+                     torch.empty((dd, 4), dtype=torch.int64, device=t_p0.device) if want_evaluations else None,
+                     torch.empty(((dd - 1) * 4,), dtype=torch.int64, device=t_p0.device)))
     for k in range(1, number_layers):
         zeta = sample_zeta()
         domain_size //= 2
         t_poly, n, t_ev, t_nodes, root = fri_layer_device(field, t_poly, n, zeta, coset_offset_sq(k), domain_size,
-                                                          want_evaluation=want_evaluations)
+                                                          want_evaluation=want_evaluations, stream=stream, buffers=bufs[k - 1])
         layers.append((t_ev, t_nodes, root, domain_size))
         append_root(root)
     t_last, _ = fri_fold_device(field, t_poly, n, sample_zeta())
