@@ -7,8 +7,11 @@ import pytest
 from oracle import oracle as O
 from tests import util
 
+import os
+
 pytestmark = pytest.mark.gpu
 FIELDS = ["stark252", "fr381", "babybear_u32", "babybear_u64", "babybear_ext4"]
+EXTRA = int(os.environ.get("LW_DIFF_EXTRA_SEEDS", "0"))   # a longer campaign: LW_DIFF_EXTRA_SEEDS=40 pytest tests/test_gpu_differential.py
 
 
 def _eq(a, b):
@@ -16,7 +19,7 @@ def _eq(a, b):
     return a.size == b.size and np.array_equal(a.reshape(-1), b.reshape(-1))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + EXTRA))
 def test_polynomial_fft_diff_random_shapes(seed):
     # polynomial_fft_diff: evaluate_fft / evaluate_offset_fft / interpolate_fft over random coefficient counts (not powers
     # of two), blow-up factors, domain sizes and offsets, all five element shapes
@@ -39,7 +42,7 @@ def test_polynomial_fft_diff_random_shapes(seed):
             assert _eq(fft.interpolate_fft(fld, exp, off), O.interpolate_fft(oid, exp, off))
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
 def test_fft_seam_diff_random_batches(seed):
     # cuda_fft_fuzzer: the backend seam on already padded slices — random log2 size, batch, stride, direction, in place
     from lambda_elliptic_curves_amd import errors, fft
@@ -64,7 +67,7 @@ def test_fft_seam_diff_random_batches(seed):
         fft.ntt(fld, util.rand_elems("stark252", 12, 1))
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 + EXTRA))
 def test_msm_diff_random_inputs(seed):
     # Pippenger == reference sum on random lengths, scalar widths and degenerate points, all four groups
     from lambda_elliptic_curves_amd import msm
@@ -87,3 +90,9 @@ def test_msm_diff_random_inputs(seed):
         got = msm.msm(crv, scalars, points)
         exp = O.msm(oid, scalars, points) if n else O.ec_neutral(oid)
         assert O.point_to_affine_ints(oid, got) == O.point_to_affine_ints(oid, exp), (name, n)
+        if n and rng.random() < 0.5:                      # the same call over a pre-normalised handle (affine rows), a random prefix
+            srs = msm.Srs(crv, points)
+            m = int(rng.integers(1, n + 1))
+            want = O.msm(oid, scalars[:m], points[:m])
+            assert O.point_to_affine_ints(oid, srs.msm(scalars[:m])) == O.point_to_affine_ints(oid, want), (name, n, m, "srs")
+            srs.close()
