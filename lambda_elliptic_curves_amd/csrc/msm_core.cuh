@@ -467,7 +467,9 @@ struct MsmRunner {
         // run length: long runs amortise the inversion (2^24 points: 5.8 ms at 128 against 8.3 ms at 32), short ones
         // keep enough work-items in flight for small sets (2^20: 1.2 ms at 32 against 2.0 ms at 128)
         static const uint32_t chk_env = [] { const char *e = tuning_env("LW_HIP_MSM_CHK"); return e ? (uint32_t)atoi(e) : 0u; }();   // tuning only
-        const uint32_t chk = chk_env ? std::min(std::max(chk_env, 1u), 1024u) : (n >= ((size_t)1 << 22) ? 128 : 32);
+        // (2^22 and 2^23 sit between the two: inside an MSM, where this kernel runs beside the sort and is the longer of the two
+        // below 2^24, 2^22 takes 13.7 ms at 32 against 14.0 at 128 and 2^23 24.1 at 64 against 24.5, profiles/r03_ab_msm_chk_mid.txt)
+        const uint32_t chk = chk_env ? std::min(std::max(chk_env, 1u), 1024u) : (n >= ((size_t)1 << 24) ? 128 : n >= ((size_t)1 << 23) ? 64 : 32);
         const uint64_t items = (n + chk - 1) / chk;
         const uint32_t blocks = (uint32_t)((items + MSM_THREADS - 1) / MSM_THREADS);
         if (c.msm_prefix.ensure(n * C::B::BYTES)) return LW_ERR_ALLOC;   // running products, one element per point
