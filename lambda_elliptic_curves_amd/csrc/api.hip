@@ -269,7 +269,7 @@ int ntt_bb_device(Context &c, lw_layout_t layout, lw_dir_t dir, const void *d_in
                   uint32_t batch, uint64_t stride, const void *coset_offset, hipStream_t stream, uint32_t in_log2);
 int broadcast_device(size_t elem_bytes, const void *d_in, void *d_out, uint64_t n, uint32_t batch, uint64_t out_stride, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream, int scalars_montgomery, int affine_points);
+               hipStream_t stream, int scalars_montgomery, int affine_points, const void *h_points = nullptr);
 int msm_normalize_device(Context &c, lw_curve_t curve, const void *d_in, size_t n, void *d_out, hipStream_t stream);
 size_t msm_affine_bytes(lw_curve_t curve, size_t n);
 int msm_fold_build(Context &c, lw_curve_t curve, void *d_rows, size_t n, uint32_t cbits, hipStream_t stream);
@@ -1181,11 +1181,9 @@ static int msm_host_entry(lw_curve_t curve, const uint64_t *scalars, size_t n_sc
     }
     hipStream_t io = en.use_lane_stream();
     if (!io) return en.rc;
-    if (n) {
-        LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
-        LW_HIP_CHECK(hipMemcpyAsync(c.host_io_b.p, points, n * pb, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
-    }
-    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, io, mont, 0);
+    // the scalars first: the sort needs nothing else, and msm_device uploads the points while it runs
+    if (n) LW_HIP_CHECK(hipMemcpyAsync(c.host_io_a.p, scalars, n * 32, hipMemcpyHostToDevice, io), LW_ERR_LAUNCH);
+    rc = msm_device(c, curve, (const uint64_t *)c.host_io_a.p, c.host_io_b.p, n, out_point, io, mont, 0, n ? points : nullptr);
     c.timings.last_msm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     c.timings.msm_calls++;
     return rc;

@@ -37,7 +37,7 @@ int ntt_cross_device(Context &c, lw_field_t field, lw_layout_t layout, lw_dir_t 
                      uint32_t log2_total, uint32_t log2_g, uint64_t j2_begin, uint64_t slice_len, uint64_t chunk_stride,
                      uint32_t batch, uint64_t batch_stride, hipStream_t stream);
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream, int scalars_montgomery, int affine_points);
+               hipStream_t stream, int scalars_montgomery, int affine_points, const void *h_points = nullptr);
 int msm_sum_points_host(lw_curve_t curve, const void *pts, size_t n, void *out);   // msm.hip
 uint32_t msm_window_bits_for(size_t n);                                              // msm.hip: the single-GPU window rule
 int msm_shard_accumulate(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, uint32_t cbits, hipStream_t s,

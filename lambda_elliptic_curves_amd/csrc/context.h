@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -110,6 +111,9 @@ struct Context {
     // (rows w * stride + i = 2^(c w) P_i) and all windows share one bucket set (msm_core.cuh build_fold)
     uint32_t msm_fold_c = 0;
     uint64_t msm_fold_stride = 0;
+    // set by msm_device for host-buffer calls: run right after the sort of the scalars is enqueued (upload of the points and
+    // their normalisation on the side stream, so that the sort runs under the upload), then cleared
+    std::function<int()> msm_after_sort;
     DeviceBuf msm_prefix;    // running products of the batch inversion (msm_to_affine_kernel), one base-field element per point
     DeviceBuf msm_affine;    // per-call affine copy of a large projective point set (msm_device)
     hipStream_t aux_stream = nullptr;   // side stream: the normalisation of the points runs beside the scalar sort

@@ -844,7 +844,12 @@ int ensure_aux_stream(Context &c) {
 }
 
 int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const void *d_points, size_t n, void *out_host,
-               hipStream_t stream, int scalars_montgomery, int affine_points) {
+               hipStream_t stream, int scalars_montgomery, int affine_points, const void *h_points) {
+    // h_points (host-buffer entry points): the points are still in host memory and d_points is the device buffer they go to.
+    // The sort needs the scalars only, so it is enqueued first and the upload runs under it (msm_after_sort below);
+    // without a normalisation the points are needed by the first kernel after the sort and go up front.
+    const size_t pbytes = lw_hip_curve_point_bytes(curve);
+    bool upload_pending = h_points != nullptr && n != 0;
     if (scalars_montgomery && n) {
         if (c.msm_scalars.ensure(n * 32)) return LW_ERR_ALLOC;
         const int bn = (curve == LW_CURVE_BN254_G1 || curve == LW_CURVE_BN254_G2);
@@ -870,8 +875,44 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         // memory-bound: side by side they take about the sum of their standalone times less 0.5 ms, LW_HIP_MSM_SIDE).
         static const bool side = [] { const char *e = tuning_env("LW_HIP_MSM_SIDE"); return !e || atoi(e) != 0; }();   // A/B only
         if (!side) {
+            if (upload_pending) {
+                LW_HIP_CHECK(hipMemcpyAsync((void *)d_points, h_points, n * pbytes, hipMemcpyHostToDevice, stream), LW_ERR_LAUNCH);
+                upload_pending = false;
+            }
             int rc = msm_normalize_device(c, curve, d_points, n, c.msm_affine.p, stream);
             if (rc) return rc;
+        } else if (upload_pending) {
+            int rc = ensure_aux_stream(c);
+            if (rc) return rc;
+            LW_HIP_CHECK(hipEventRecord(c.aux_fork, stream), LW_ERR_LAUNCH);
+            LW_HIP_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_fork, 0), LW_ERR_LAUNCH);
+            const void *src = d_points;
+            // in chunks of 2^20 points: chunk k is normalised (second side stream) while chunk k + 1 is on the bus, so that what
+            // is left after the last byte arrives is one chunk's normalisation, not the whole set's
+            c.msm_after_sort = [&c, curve, src, h_points, n, pbytes]() -> int {
+                const size_t CHUNK = (size_t)1 << 20, astride = msm_affine_bytes(curve, 1);
+                hipEvent_t ev = nullptr;
+                if (!c.sync_pool.empty()) { ev = c.sync_pool.back(); c.sync_pool.pop_back(); }
+                else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return LW_ERR_LAUNCH; }
+                int r = LW_OK;
+                for (size_t off = 0; off < n && !r; off += CHUNK) {
+                    const size_t m = n - off < CHUNK ? n - off : CHUNK;
+                    const char *d = (const char *)src + off * pbytes;
+                    if (hipMemcpyAsync((void *)d, (const char *)h_points + off * pbytes, m * pbytes, hipMemcpyHostToDevice, c.aux_stream) != hipSuccess ||
+                        hipEventRecord(ev, c.aux_stream) != hipSuccess || hipStreamWaitEvent(c.aux_hi, ev, 0) != hipSuccess) {
+                        set_error("upload of the points failed");
+                        r = LW_ERR_LAUNCH;
+                        break;
+                    }
+                    r = msm_normalize_device(c, curve, d, m, (char *)c.msm_affine.p + off * astride, c.aux_hi);
+                }
+                c.sync_pool.push_back(ev);
+                if (r) return r;
+                LW_HIP_CHECK(hipEventRecord(c.aux_join, c.aux_hi), LW_ERR_LAUNCH);
+                return LW_OK;
+            };
+            upload_pending = false;
+            join = c.aux_join;
         } else {
         {
             int rc = ensure_aux_stream(c);
@@ -892,6 +933,8 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         d_points = c.msm_affine.p;
         affine_points = 1;
     }
+    if (upload_pending)   // no normalisation: the accumulation reads the rows as they are
+        LW_HIP_CHECK(hipMemcpyAsync((void *)d_points, h_points, n * pbytes, hipMemcpyHostToDevice, stream), LW_ERR_LAUNCH);
     int rc;
     switch (curve) {
         case LW_CURVE_BLS12_381_G1: rc = msm_run_bls12381_g1(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
@@ -900,7 +943,11 @@ int msm_device(Context &c, lw_curve_t curve, const uint64_t *d_scalars, const vo
         case LW_CURVE_BLS12_381_G2: rc = msm_run_bls12381_g2(c, stream, d_scalars, d_points, n, out_host, affine_points, join); break;
         default: set_error("bad curve %d", (int)curve); return LW_ERR_BAD_ARG;
     }
-    if (rc && join) (void)hipStreamSynchronize(c.aux_stream);   // do not leave the side stream running into a failed call's buffers
+    c.msm_after_sort = nullptr;                                  // (a run that failed before its sort never took it)
+    if (rc && join) {   // do not leave the side streams running into a failed call's buffers
+        (void)hipStreamSynchronize(c.aux_stream);
+        if (c.aux_hi) (void)hipStreamSynchronize(c.aux_hi);
+    }
     return rc;
 }
 

@@ -904,6 +904,12 @@ struct MsmRunner {
             msm_launch_digits(c, (const uint32_t *)d_scalars, (uint64_t)n, cbits, W, dig, stream);
             rc = launch_sort(sl[0], dig, n, cbits, stream);
             if (rc) return rc;
+            if (c.msm_after_sort) {   // host-buffer call: the points are uploaded (and normalised) while the sort above runs
+                auto hook = std::move(c.msm_after_sort);
+                c.msm_after_sort = nullptr;
+                rc = hook();
+                if (rc) return rc;
+            }
             LW_HIP_CHECK(hipStreamSynchronize(stream), LW_ERR_LAUNCH);
             if (points_ready) LW_HIP_CHECK(hipStreamWaitEvent(stream, points_ready, 0), LW_ERR_LAUNCH);   // normalised points
             hipEvent_t sorted1 = nullptr;
