@@ -202,6 +202,29 @@ def test_msm_large_input_with_identity_rows():
     assert aff(oid, small) == aff(oid, O.msm(oid, sc[:m], with_id[:m]))
 
 
+@pytest.mark.parametrize("name,log_n", [("bls12_381_g1", 21), ("bn254_g2", 19)])
+def test_msm_host_buffers_large_equals_device_resident(name, log_n):
+    """Host-buffer calls of normalised sizes upload the points in chunks of 2^20 under the sort and normalise each chunk as it
+    arrives (csrc/msm.hip msm_device, h_points): a size that is not a multiple of the chunk, with identity rows at the chunk
+    seams, must give the device-resident call's result; a prefix is anchored to the oracle."""
+    import torch
+    from lambda_elliptic_curves_amd import msm
+    crv, oid = util.curve_pairs()[name]
+    n, base_n = (1 << log_n) + 777, 1 << 11
+    _, base = util.msm_case(oid, base_n, 61)
+    rng = np.random.default_rng(62)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    pts = np.tile(base, (n // base_n + 1, 1))[:n].copy()
+    for i in (0, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, n - 1):
+        if i < n:
+            pts[i] = O.ec_neutral(oid)
+    host = msm.msm(crv, sc, pts)
+    dev = msm.msm_device(crv, torch.from_numpy(sc.view(np.int64)).cuda(), torch.from_numpy(pts.view(np.int64)).cuda(), n)
+    assert aff(oid, host) == aff(oid, dev)
+    m = 1 << 11
+    assert aff(oid, msm.msm(crv, sc[:m], pts[:m])) == aff(oid, O.msm(oid, sc[:m], pts[:m]))
+
+
 @pytest.mark.parametrize("name", CURVES)
 def test_batched_group_law_outer_addition(name):
     # lw_hip_ec_add_outer_device == IsGroup::operate_with (short_weierstrass/point.rs:171-207) pair by pair, including
